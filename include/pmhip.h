@@ -1,0 +1,263 @@
+/*
+ * pmhip.h -- C ABI of libpaintmind_hip.so: the MI355X (gfx950) generation path of PaintMind.
+ *
+ * The reference (Qiyuan-Ge/PaintMind) has no FFI: its boundary is a Python object protocol whose
+ * arithmetic is delegated to PyTorch ATen.  This header is the boundary a maintainer would bind
+ * instead (ctypes stub in INTEGRATION.md).  Every entry point cites the reference code whose
+ * arithmetic it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless the name ends in _host
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream
+ *   - return value: 0 = ok, otherwise a PMHIP_E* code; pmhip_last_error() gives the message
+ *     (thread-local).  Nothing throws across this boundary.
+ *   - the caller owns every tensor and every weight; the library owns only its handles'
+ *     workspace arenas (hipMalloc'ed, grown on demand, freed by *_destroy)
+ *   - handles are single-stream objects, not thread-safe
+ *   - matrices are row-major; "T" below is the handle's compute dtype (PMHIP_F32 or PMHIP_BF16);
+ *     weights are stored [out_features, in_features] exactly like torch.nn.Linear
+ *   - GEMM reduction widths (K) must be multiples of 64 elements; the host packer zero-pads
+ */
+#ifndef PMHIP_H
+#define PMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMHIP_ABI_VERSION 1
+
+enum { PMHIP_OK = 0, PMHIP_EINVAL = 1, PMHIP_EHIP = 2, PMHIP_ENOMEM = 3, PMHIP_ESTATE = 4 };
+enum { PMHIP_F32 = 0, PMHIP_BF16 = 1 };
+/* what a block of packed projection rows is, for pmhip_gemm_heads */
+enum { PMHIP_PART_Q = 0, PMHIP_PART_K = 1, PMHIP_PART_V = 2 };
+
+typedef void* pmhip_stream;
+
+int pmhip_abi_version(void);
+const char* pmhip_last_error(void);
+/* number of compute units / LDS bytes per workgroup / gcnArchName of `device` */
+int pmhip_device_info(int device, int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator level (stateless).  These are what the reference's operator plug-point would call
+ * (Layer.ATTENTION_MODES, stage1/layers.py:41-48, stage2/transformer.py:29-36; SwiGLU swap,
+ * modules/mlp.py:34-40).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* out[M,N] = A[M,K] . W[N,K]^T (+ bias[N]) (+ residual[m % res_rows, N]);  nn.Linear forward
+ * (modules/attention.py:46-49,59; stage1/vqmodel.py:23,28; stage1/layers.py:149;
+ * stage2/transformer.py:81,85,91).  A, W are `dtype`; bias/residual fp32 or NULL; out is
+ * `out_dtype`.  res_rows lets one [tokens, N] table (a position embedding,
+ * stage1/layers.py:108,146, stage2/transformer.py:82) be added to every image. */
+int pmhip_gemm(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
+               const float* residual, int ldr, int res_rows, void* out, int ldo, int out_dtype,
+               int M, int N, int K, pmhip_stream stream);
+
+/* SwiGLU first half (modules/mlp.py:27-30): out[M,Hp] = silu(x1) * x2 with
+ * [x1|x2] = A . W12^T + b12.  W12p/b12p are the *packed* form: rows interleaved in groups of 16
+ * (16 rows of x1, the matching 16 rows of x2, ...), hidden width zero-padded to Hp (mult. of 64). */
+int pmhip_gemm_swiglu(int dtype, const void* A, int lda, const void* W12p, const float* b12p,
+                      void* out, int ldo, int M, int Hp, int K, pmhip_stream stream);
+
+/* Head-split projection (modules/attention.py:46-52): A[M,K] . W[nparts*inner,K]^T, no bias,
+ * written per part as  Q -> [B,H,tokens,64] * q_scale ;  K -> [B,H,tokens_pad,64] ;
+ * V -> transposed [B,H,64,tokens_pad].  M = B*tokens, inner = heads*64 (dim_head is 64). */
+int pmhip_gemm_heads(int dtype, const void* A, int lda, const void* W, int ldw, int M, int K,
+                     int heads, int tokens, int tokens_pad, int nparts, const int* part_kinds_host,
+                     void* const* part_outs_host, float q_scale, pmhip_stream stream);
+
+/* softmax(Q K^T) V per (batch, head), no mask, no dropout (modules/attention.py:51-58; the same
+ * maths as xformers.ops.memory_efficient_attention at :100).  Q is already scaled.  Layouts as
+ * written by pmhip_gemm_heads.  out[B*Nq, heads*64] (`dtype`), head-major inside a row
+ * ('(b h) n d -> b n (h d)', attention.py:58).  use_exp2 != 0: Q carries an extra log2(e) factor
+ * and the kernel exponentiates with exp2. */
+int pmhip_attention(int dtype, const void* Q, const void* K, const void* Vt, void* out, int ldo,
+                    int B, int heads, int Nq, int Nkv, int Nkv_pad, int use_exp2,
+                    pmhip_stream stream);
+
+/* torch.nn.LayerNorm over the last dim, eps inside the sqrt (stage1/layers.py:49,51,89,128;
+ * stage2/transformer.py:37,39,41,62).  x fp32 [M,D] -> out (`out_dtype`). */
+int pmhip_layernorm(const float* x, const float* gamma, const float* beta, float eps, void* out,
+                    int out_dtype, int M, int D, pmhip_stream stream);
+
+/* Non-overlapping PxP patches of img[B,C,H,W] (fp32) as GEMM rows: out[B*(H/P)*(W/P), C*P*P],
+ * column order (c, kh, kw) = the flattened Conv2d weight (stage1/layers.py:81-84,107). */
+int pmhip_patchify(const float* img, void* out, int out_dtype, int B, int C, int H, int W, int P,
+                   pmhip_stream stream);
+
+/* 'b (h w) (p1 p2 c) -> b c (h p1) (w p2)' then clamp(lo,hi) (stage1/layers.py:150;
+ * stage1/vqmodel.py:30).  y fp32 [B*(H/P)*(W/P), P*P*C] -> img fp32 [B,C,H,W]. */
+int pmhip_unpatchify_clamp(const float* y, float* img, int B, int C, int H, int W, int P, float lo,
+                           float hi, pmhip_stream stream);
+
+/* fp32 [M,K] -> `out_dtype` [M,Kpad], zero-padded columns (feeds K<64 projections). */
+int pmhip_convert_pad(const float* in, int K, void* out, int out_dtype, int Kpad, int M,
+                      pmhip_stream stream);
+
+/* out[m,:] = x[m,:] + table[m % table_rows,:], all fp32 (x + position_embedding,
+ * stage1/layers.py:108,146; stage2/transformer.py:82). */
+int pmhip_add_rows(const float* x, const float* table, int table_rows, float* out, int M, int D,
+                   pmhip_stream stream);
+
+/* Row gather out[m,:] = table[ids[m],:] (nn.Embedding: stage1/quantize.py:41, generate.py:148-157),
+ * table fp32 [V,E], ids int64, out `out_dtype` [M,Kpad] zero-padded. */
+int pmhip_embed_rows(const float* table, const int64_t* ids, void* out, int out_dtype, int Kpad,
+                     int M, int V, int E, pmhip_stream stream);
+
+/* Codebook preparation, hoisted out of the per-call path: en = W / max(||W||,1e-12) row-wise and
+ * sq[j] = sum(en[j]^2) (stage1/quantize.py:5-6,21,24-25). */
+int pmhip_vq_prepare(const float* codebook, float* en, float* sq, int V, int E,
+                     pmhip_stream stream);
+
+/* VectorQuantizer.forward (stage1/quantize.py:18-38) on z fp32 [M,E] (the prev_quant output):
+ * zn = l2norm(z); d = sum(zn^2) + sq - 2 zn.en^T; idx = first argmin; zq = en[idx];
+ * z_out = zn + (zq - zn); loss = beta*mean((zq-zn)^2) + mean((zq-zn)^2).
+ * The arithmetic order is fixed (sequential fmaf over E) and restated in oracle/vq_ref.c, so idx
+ * is bit-exact against the oracle.  `scratch` >= pmhip_vq_scratch_bytes(M,V) bytes. */
+size_t pmhip_vq_scratch_bytes(int M, int V);
+int pmhip_vq_quantize(const float* z, const float* en, const float* sq, float beta, float* z_out,
+                      int64_t* idx_out, float* loss_out, void* scratch, int M, int V, int E,
+                      pmhip_stream stream);
+
+/* One MaskGIT sampling pass over logits rows (generate.py:163-173 with helpers :29-46):
+ * top-k filter, gumbel-argmax at `temperature`, confidence from the UNfiltered softmax, merge into
+ * the previously masked positions.  noise: NULL -> counter-based Philox keyed by
+ * (seed, step, row_base+row, column); else fp32 [M,V] uniform(0,1) samples (parity mode, the
+ * reference's torch.zeros_like(t).uniform_(0,1), generate.py:41).
+ * Outputs: pred[M] (all positions, what the image is decoded from, generate.py:165),
+ * ids_out[M] = where(ids_in==mask_id, pred, ids_in), score[M] = is_mask ? 1-p[pred] : -1e5.
+ * ids_out may alias ids_in.  Ties: (value desc, index asc). 1 <= topk <= 64. */
+int pmhip_sample_rows(const float* logits, int ldl, const int64_t* ids_in, int64_t mask_id,
+                      int topk, float temperature, const float* noise, uint64_t seed,
+                      uint32_t step, uint64_t row_base, int64_t* pred_out, int64_t* ids_out,
+                      float* score_out, int M, int V, pmhip_stream stream);
+
+/* Re-mask the num_mask least confident tokens of every image (generate.py:175-179):
+ * ids[b, topk(scores[b], num_mask)] = mask_id.  Ties: (score desc, index asc). N <= 4096. */
+int pmhip_remask(int64_t* ids, const float* scores, int num_mask, int64_t mask_id, int B, int N,
+                 pmhip_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model level.  Weight tables are filled by the host packer (paintmind_amd/engine.py) from the
+ * reference's state_dict layout.
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct pmhip_layer_weights {
+    const float* ln1_g; const float* ln1_b;    /* norm1                                         */
+    const void* wqkv;                          /* attn1 to_q|to_k|to_v rows, [3*inner, dim] T   */
+    const void* wo; const float* bo;           /* attn1 to_out.0  [dim, inner] T, [dim]         */
+    const float* lnx_g; const float* lnx_b;    /* stage 2 only: norm2 (else NULL)               */
+    const void* wqkv2;                         /* stage 2 only: attn2 to_q|to_k|to_v            */
+    const void* wo2; const float* bo2;         /* stage 2 only: attn2 to_out.0                  */
+    const float* ln2_g; const float* ln2_b;    /* the norm in front of the FFN                  */
+    const void* w12p; const float* b12p;       /* packed SwiGLU w12, [2*hidden_pad, dim] T      */
+    const void* w3p; const float* b3;          /* w3 zero-padded in K, [dim, hidden_pad] T      */
+} pmhip_layer_weights;
+
+typedef struct pmhip_tower_cfg {
+    int dim, depth, heads, hidden_pad;         /* dim_head is fixed at 64                       */
+} pmhip_tower_cfg;
+
+typedef struct pmhip_vqgan_cfg {
+    int image_size, patch_size, channels;
+    int n_embed, embed_dim;
+    float beta;
+    pmhip_tower_cfg enc, dec;
+} pmhip_vqgan_cfg;
+
+typedef struct pmhip_vqgan_weights {
+    const void* patch_w;                       /* conv weight as [dim, C*P*P] T                 */
+    const float* enc_pos;                      /* [tokens, dim]                                 */
+    const float* pre_g; const float* pre_b;    /* encoder.norm_pre                              */
+    const pmhip_layer_weights* enc_layers;     /* host array [enc.depth]                        */
+    const void* prevq_w; const float* prevq_b; /* [embed_dim, dim] T                            */
+    const float* codebook_n;                   /* pmhip_vq_prepare output, [n_embed, embed_dim] */
+    const float* codebook_sq;                  /* [n_embed]                                     */
+    const void* postq_w; const float* postq_b; /* [dim, 64] T (K zero-padded)                   */
+    const float* dec_pos;
+    const pmhip_layer_weights* dec_layers;
+    const float* dn_g; const float* dn_b;      /* decoder.norm                                  */
+    const void* proj_w; const float* proj_b;   /* [P*P*C, dim] T                                */
+} pmhip_vqgan_weights;
+
+typedef struct pmhip_vqgan pmhip_vqgan;
+
+/* VQModel (stage1/vqmodel.py:7-44).  The tables are copied; the pointed-to weights are not. */
+int pmhip_vqgan_create(pmhip_vqgan** out, int device, int dtype, const pmhip_vqgan_cfg* cfg,
+                       const pmhip_vqgan_weights* w);
+void pmhip_vqgan_destroy(pmhip_vqgan* h);
+/* VQModel.encode (vqmodel.py:21-25): img fp32 [B,C,H,W] -> z fp32 [B,N,E], idx int64 [B,N], loss[1] */
+int pmhip_vqgan_encode(pmhip_vqgan* h, const float* img, int B, float* z_out, int64_t* idx_out,
+                       float* loss_out, pmhip_stream stream);
+/* VQModel.decode (vqmodel.py:27-30): z fp32 [B,N,E] -> img fp32 [B,C,H,W] clamped to [-1,1] */
+int pmhip_vqgan_decode(pmhip_vqgan* h, const float* z, int B, float* img_out, pmhip_stream stream);
+/* VQModel.decode_from_indice (vqmodel.py:38-41) */
+int pmhip_vqgan_decode_indices(pmhip_vqgan* h, const int64_t* idx, int B, float* img_out,
+                               pmhip_stream stream);
+/* Encoder.forward / Decoder.forward alone (stage1/layers.py:106-112,145-152); the decoder variant
+ * takes the post_quant output x fp32 [B,N,dim] and returns the un-clamped image. */
+int pmhip_vqgan_encoder_forward(pmhip_vqgan* h, const float* img, int B, float* x_out,
+                                pmhip_stream stream);
+int pmhip_vqgan_decoder_forward(pmhip_vqgan* h, const float* x, int B, float* img_out,
+                                pmhip_stream stream);
+
+typedef struct pmhip_s2_cfg {
+    int tokens, embed_dim, n_embed, context_dim, context_dim_pad;  /* context_dim_pad: mult. of 64 */
+    pmhip_tower_cfg tower;
+} pmhip_s2_cfg;
+
+typedef struct pmhip_s2_weights {
+    const float* tok_table;                    /* [n_embed+1, embed_dim]: RAW codebook rows, then
+                                                  mask_token (generate.py:148-157)              */
+    const void* tokproj_w; const float* tokproj_b;   /* [dim, 64] T                            */
+    const float* pos;                          /* [tokens, dim]                                 */
+    const void* ctxproj_w;                     /* [dim, context_dim_pad] T, NULL when Identity  */
+    const pmhip_layer_weights* layers;         /* host array [depth]                            */
+    const float* norm_g; const float* norm_b;
+    const void* logits_w; const float* logits_b;     /* [n_embed, dim] T                       */
+} pmhip_s2_weights;
+
+typedef struct pmhip_s2 pmhip_s2;
+
+/* CondTransformer (stage2/transformer.py:52-93) */
+int pmhip_s2_create(pmhip_s2** out, int device, int dtype, const pmhip_s2_cfg* cfg,
+                    const pmhip_s2_weights* w);
+void pmhip_s2_destroy(pmhip_s2* h);
+/* CondTransformer.forward (transformer.py:80-93): tokens fp32 [B,N,E]; context fp32 [B,L,ctx] or
+ * NULL (then attn2 is a second self-attention, modules/attention.py:47); logits fp32 [B,N,V]. */
+int pmhip_s2_forward(pmhip_s2* h, const float* tokens, const float* context, int L, int B,
+                     float* logits_out, pmhip_stream stream);
+
+/* Pipeline.sample (generate.py:159-181), one MaskGIT step on ids int64 [B,N] in place.
+ * img_out may be NULL (skip the ViT decode of generate.py:165); pred_out/score_out may be NULL. */
+int pmhip_pipeline_sample(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context, int L,
+                          int B, int topk, float temperature, int num_mask, const float* noise,
+                          uint64_t seed, uint32_t step, uint64_t image_base, float* img_out,
+                          int64_t* pred_out, float* score_out, pmhip_stream stream);
+
+/* Pipeline.generate's loop body (generate.py:189-196) for T steps.  temps_host[T], nmask_host[T]
+ * are the per-step temperature and num_token_masked the caller derived exactly as the reference
+ * does (generate.py:191-193,175); decode_host[T] != 0 selects the steps whose image is produced,
+ * written consecutively into imgs_out [n_decoded, B, C, H, W].  The context projection and the
+ * cross-attention K/V of the static context are computed once (the reference recomputes them every
+ * step, transformer.py:84-85).  use_graph != 0 captures each step into a hipGraph. */
+int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context,
+                            int L, int B, int T, const float* temps_host, const int* nmask_host,
+                            const unsigned char* decode_host, int topk, uint64_t seed,
+                            uint64_t image_base, float* imgs_out, int use_graph,
+                            pmhip_stream stream);
+
+/* Per-kernel timing hook used by bench.py: when enabled, every kernel launch of the named family
+ * is bracketed by hipEvents on its own stream and accumulated (count, total ms). */
+int pmhip_timing_enable(int on);
+int pmhip_timing_reset(void);
+/* family: "gemm", "attention", "layernorm", "sample", "vq", "rowops"; returns PMHIP_EINVAL if unknown */
+int pmhip_timing_get(const char* family, int* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMHIP_H */

@@ -1,0 +1,15 @@
+"""paintmind_amd -- MI355X-native generation path of PaintMind behind the reference's Python API.
+
+    import paintmind_amd as pm
+    model = pm.create_model(arch='vqgan', version='vit-s-vqgan', pretrained=False).to('cuda')
+    z, loss, idx = model.encode(x); rec = model.decode(z)
+
+Mirrors reference paintmind/__init__.py:1-7 for the inference surface (Config, create_model,
+create_pipeline_for_train).  The trainers / transforms / demo figure of the reference are out of scope
+(SURVEY.md section 8).
+"""
+from .version import __version__
+from .config import Config, ver2cfg
+from .factory import create_model, create_pipeline_for_train
+
+__all__ = ["__version__", "Config", "ver2cfg", "create_model", "create_pipeline_for_train"]

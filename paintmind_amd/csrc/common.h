@@ -1,0 +1,132 @@
+// Shared device/host helpers for libpaintmind_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pmhip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef unsigned short bf16_t;  // storage type of a bfloat16 element
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (never throws across the C ABI)
+// ---------------------------------------------------------------------------------------------
+void pm_set_error(const char* fmt, ...);
+
+#define PM_HIP(expr)                                                                    \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            pm_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return PMHIP_EHIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define PM_REQUIRE(cond, ...)                  \
+    do {                                       \
+        if (!(cond)) {                         \
+            pm_set_error(__VA_ARGS__);         \
+            return PMHIP_EINVAL;               \
+        }                                      \
+    } while (0)
+
+#define PM_TRY(expr)                \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != PMHIP_OK) return _rc; \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// per-family kernel timing (bench.py's roofline leg).  Off by default: zero overhead.
+// ---------------------------------------------------------------------------------------------
+enum PmFamily { FAM_GEMM = 0, FAM_ATTENTION, FAM_LAYERNORM, FAM_SAMPLE, FAM_VQ, FAM_ROWOPS, FAM_COUNT };
+struct PmTimer {
+    PmTimer(int family, hipStream_t s);
+    ~PmTimer();
+    int family;
+    hipStream_t stream;
+    hipEvent_t e0;
+    bool on;
+};
+extern bool g_pm_timing_on;
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even, NaN preserved (what torch's float->bfloat16 cast does)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> __device__ __forceinline__ T from_f32(float f);
+template <> __device__ __forceinline__ float from_f32<float>(float f) { return f; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) { return f32_to_bf16(f); }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+
+// store 4 consecutive elements (p is 4-element aligned)
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+
+// One 16-byte operand chunk per lane feeds the matrix core:
+//   bf16: 8 k-values  -> one  v_mfma_f32_16x16x32_bf16
+//   f32 : 4 k-values  -> four v_mfma_f32_16x16x4_f32 (exact f32, == an fmaf chain)
+// `first` supplies the ROWS of the 16x16 result, `second` the COLUMNS; result element
+// (row 4*(lane>>4)+r, col lane&15) lands in acc[r].  The k <-> (lane>>4, element) assignment is
+// identical for both operands, so any consistent chunk layout contracts correctly.
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int kElemsPerChunk = 8;
+    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& first, const uint4& second) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, first),
+                                                      __builtin_bit_cast(bf16x8_t, second), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int kElemsPerChunk = 4;
+    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& first, const uint4& second) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(first.x), __uint_as_float(second.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(first.y), __uint_as_float(second.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(first.z), __uint_as_float(second.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(first.w), __uint_as_float(second.w), acc, 0, 0, 0);
+    }
+};
+
+// async global -> LDS copy of 16 B per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t dtype_size(int dtype) { return dtype == PMHIP_BF16 ? 2 : 4; }

@@ -1,0 +1,207 @@
+// MaskGIT sampling tail (reference generate.py:163-179 with helpers :29-46), HBM-bound.
+//
+// sample_rows: ONE read of each logits row (32 KiB for 8192 fp32 classes).  One wave owns a row,
+// the row lives in registers (16 B per lane per load, 1 KiB per wave-instruction, fully
+// coalesced).  From that single residency the wave derives: the softmax normaliser (max, sum exp),
+// the top-k candidates (k rounds of a wave-wide lexicographic arg-max -- no sort, no scatter of a
+// -inf tensor as the reference does at :33-37), the gumbel-perturbed arg-max among the k candidates
+// (noise is only needed at those k positions: every other position is -inf in the reference), the
+// confidence of the unfiltered softmax at the sampled id, and the merge into the masked positions.
+//
+// remask: per image, the num_mask highest scores get the mask id (generate.py:175-179); bitonic sort
+// of 64-bit (score, reversed index) keys in LDS gives the exact (score desc, index asc) order.
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+struct Cand { float v; int i; };
+
+// total order used everywhere: larger value first, then smaller index
+__device__ __forceinline__ bool before(float av, int ai, float bv, int bi) {
+    return (av > bv) || (av == bv && ai < bi);
+}
+
+__device__ __forceinline__ Cand wave_best(Cand c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(c.v, o, 64);
+        const int oi = __shfl_xor(c.i, o, 64);
+        if (before(ov, oi, c.v, c.i)) { c.v = ov; c.i = oi; }
+    }
+    return c;
+}
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// log(t.clamp(min=1e-20)) twice, negated (generate.py:29-30,40-42)
+__device__ __forceinline__ float gumbel_from_uniform(float u) {
+    const float inner = -logf(fmaxf(u, 1e-20f));
+    return -logf(fmaxf(inner, 1e-20f));
+}
+
+template <int NV4>
+__global__ __launch_bounds__(THREADS) void sample_rows_kernel(
+    const float* __restrict__ logits, int ldl, const int64_t* __restrict__ ids_in, int64_t mask_id, int topk,
+    float temperature, const float* __restrict__ noise, uint64_t seed, uint32_t step, uint64_t row_base,
+    int64_t* __restrict__ pred_out, int64_t* __restrict__ ids_out, float* __restrict__ score_out, int M, int V) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;                                  // whole wave exits together
+    const float* lrow = logits + (size_t)row * ldl;
+
+    float x[NV4 * 4];
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (col < V) v = *reinterpret_cast<const float4*>(lrow + col);
+        x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+    }
+    // ---- softmax normaliser
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV4 * 4; ++i) mx = fmaxf(mx, x[i]);
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4 * 4; ++i) se += expf(x[i] - mx);
+    se = wave_sum(se);
+
+    // ---- top-k by k rounds of "best element strictly after the previous winner"
+    float pv = INFINITY;
+    int pi = -1;
+    Cand mine{-INFINITY, 0x7fffffff};                      // candidate r is kept by lane r
+#pragma unroll 1
+    for (int r = 0; r < topk; ++r) {
+        Cand c{-INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = x[4 * i + e];
+                const int idx = (i * 64 + lane) * 4 + e;
+                const bool eligible = (idx < V) && before(pv, pi, v, idx);
+                if (eligible && before(v, idx, c.v, c.i)) { c.v = v; c.i = idx; }
+            }
+        }
+        c = wave_best(c);
+        pv = c.v; pi = c.i;
+        if (lane == r) mine = c;
+    }
+    // ---- gumbel arg-max among the candidates (lane r evaluates candidate r)
+    Cand pert{-INFINITY, 0x7fffffff};
+    if (lane < topk && mine.i < V) {
+        float u;
+        if (noise) {
+            u = noise[(size_t)row * V + mine.i];
+        } else {
+            const uint64_t grow = row_base + (uint64_t)row;
+            const uint4 rnd = philox4x32_10(make_uint4((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)mine.i, step),
+                                            make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+            u = (float)(rnd.x >> 8) * (1.0f / 16777216.0f);
+        }
+        pert.v = mine.v / fmaxf(temperature, 1e-10f) + gumbel_from_uniform(u);
+        pert.i = mine.i;
+    }
+    // remember each candidate's raw logit: the winner's lane broadcasts it afterwards
+    const Cand win = wave_best(pert);
+    const unsigned long long owner = __ballot(lane < topk && mine.i == win.i);
+    const int src = owner ? __ffsll((long long)owner) - 1 : 0;
+    const float raw = __shfl(mine.v, src, 64);
+
+    if (lane == 0) {
+        const int64_t pred = win.i;
+        const int64_t cur = ids_in[row];
+        const bool is_mask = (cur == mask_id);
+        const float p = expf(raw - mx) / se;
+        if (pred_out) pred_out[row] = pred;
+        ids_out[row] = is_mask ? pred : cur;
+        if (score_out) score_out[row] = is_mask ? (1.0f - p) : -1e5f;
+    }
+}
+
+__device__ __forceinline__ uint32_t orderable(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(THREADS) void remask_kernel(int64_t* __restrict__ ids, const float* __restrict__ scores,
+                                                         int num_mask, int64_t mask_id, int N, int Npow2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
+    const int b = blockIdx.x;
+    const float* sc = scores + (size_t)b * N;
+    for (int i = threadIdx.x; i < Npow2; i += THREADS)
+        key[i] = i < N ? (((unsigned long long)orderable(sc[i]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i)) : 0ull;
+    __syncthreads();
+    // bitonic sort, descending
+    for (int k = 2; k <= Npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < Npow2; i += THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = key[i], c = key[ixj];
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? (a < c) : (a > c)) { key[i] = c; key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int nm = num_mask < 1 ? 1 : (num_mask > N ? N : num_mask);
+    const unsigned long long thr = key[nm - 1];
+    for (int i = threadIdx.x; i < N; i += THREADS) {
+        const unsigned long long k = ((unsigned long long)orderable(sc[i]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
+        if (k >= thr) ids[(size_t)b * N + i] = mask_id;
+    }
+}
+
+}  // namespace
+
+extern "C" int pmhip_sample_rows(const float* logits, int ldl, const int64_t* ids_in, int64_t mask_id, int topk,
+                                 float temperature, const float* noise, uint64_t seed, uint32_t step,
+                                 uint64_t row_base, int64_t* pred_out, int64_t* ids_out, float* score_out, int M,
+                                 int V, pmhip_stream stream) {
+    PM_REQUIRE(logits && ids_in && ids_out, "sample_rows: null pointer");
+    PM_REQUIRE(M > 0 && V > 0 && V % 4 == 0 && ldl % 4 == 0 && ldl >= V, "sample_rows: bad shape M=%d V=%d ldl=%d", M, V, ldl);
+    PM_REQUIRE(topk >= 1 && topk <= 64 && topk <= V, "sample_rows: topk=%d must be in [1, min(64,V)]", topk);
+    PM_REQUIRE(V <= 16384, "sample_rows: V=%d > 16384 unsupported", V);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(ceil_div(M, THREADS / 64)), block(THREADS);
+    PmTimer tm(FAM_SAMPLE, s);
+#define PM_SAMPLE(NV4)                                                                                              \
+    hipLaunchKernelGGL((sample_rows_kernel<NV4>), grid, block, 0, s, logits, ldl, ids_in, mask_id, topk, temperature, \
+                       noise, seed, step, row_base, pred_out, ids_out, score_out, M, V)
+    if (V <= 256) PM_SAMPLE(1);
+    else if (V <= 1024) PM_SAMPLE(4);
+    else if (V <= 8192) PM_SAMPLE(32);
+    else PM_SAMPLE(64);
+#undef PM_SAMPLE
+    PM_HIP(hipGetLastError());
+    return PMHIP_OK;
+}
+
+extern "C" int pmhip_remask(int64_t* ids, const float* scores, int num_mask, int64_t mask_id, int B, int N,
+                            pmhip_stream stream) {
+    PM_REQUIRE(ids && scores, "remask: null pointer");
+    PM_REQUIRE(B > 0 && N > 0 && N <= 4096, "remask: bad shape B=%d N=%d (N <= 4096)", B, N);
+    int np2 = 1;
+    while (np2 < N) np2 <<= 1;
+    hipStream_t s = (hipStream_t)stream;
+    PmTimer tm(FAM_SAMPLE, s);
+    hipLaunchKernelGGL(remask_kernel, dim3(B), dim3(THREADS), (size_t)np2 * 8, s, ids, scores, num_mask, mask_id, N, np2);
+    PM_HIP(hipGetLastError());
+    return PMHIP_OK;
+}

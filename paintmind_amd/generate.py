@@ -1,0 +1,192 @@
+"""Pipeline: frozen VQGAN + text tower + CondTransformer and the MaskGIT decode loop
+(reference paintmind/generate.py:49-236), driven through the native engine.
+
+Kept 1:1 with the reference: constructor wiring and parameter names, ``to_latent`` /
+``tokens2logits`` / ``ids2tokens`` / ``sample`` / ``generate`` / ``inpaint`` / ``outpaint`` signatures,
+return structures and the quirks listed in SURVEY.md section 8(a) (image decoded from the predictions at
+ALL positions, confidence from the unfiltered softmax, >= 1 token re-masked on the last step,
+``generate`` returning only the steps with ``step % save_interval == 0`` as CPU tensors).
+Training-only members (forward / loss / random_masking, generate.py:78-146) are out of scope.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+from .config import ver2cfg
+from .engine import S2Engine
+from .stage2 import CondTransformer
+
+
+def exists(x):
+    return x is not None
+
+
+def mask_schedule(ratio):
+    """cosine schedule, evaluated in float64 like the reference (generate.py:25-26)."""
+    return np.cos(math.pi / 2. * ratio)
+
+
+def num_token_masked(mask_ratio, num_tokens):
+    """generate.py:175 -- max(int(mask_ratio * num_tokens), 1); accepts numpy scalars, tensors, floats."""
+    r = mask_ratio * num_tokens
+    r = r.item() if hasattr(r, "item") else r
+    return max(int(r), 1)
+
+
+T5_VERSION = {'t5-l': 'google/flan-t5-large', 't5-xl': 'google/flan-t5-xl', 't5-xxl': 'google/flan-t5-xxl'}
+T5_TXT_DIM = {'t5-l': 1024, 't5-xl': 2048}      # no 't5-xxl' entry, as in the reference (generate.py:53)
+
+
+class Pipeline(nn.Module):
+    def __init__(self, config, stage1_pretrained=True, stage1_checkpoint_path=None, text_model=None):
+        super().__init__()
+        from .factory import create_model
+        self.vqgan = create_model(arch='vqgan', version=config.stage1, pretrained=stage1_pretrained,
+                                  checkpoint_path=stage1_checkpoint_path)
+        self.vqgan.freeze()
+
+        context_dim = getattr(config, "context_dim", None) or T5_TXT_DIM[config.t5]
+        if text_model is not None:
+            self.text_model = text_model
+        elif getattr(config, "text_model", "t5") == "none":
+            from .modules.encoder import SyntheticTextEmbedder
+            self.text_model = SyntheticTextEmbedder(context_dim)
+        else:
+            from .modules.encoder import T5TextEmbedder
+            self.text_model = T5TextEmbedder(version=T5_VERSION[config.t5], freeze=True)
+
+        vq_cfg = ver2cfg[config.stage1]
+        self.image_size = vq_cfg['enc']['image_size']
+        self.patch_size = vq_cfg['enc']['patch_size']
+        self.num_tokens = (self.image_size // self.patch_size) ** 2
+
+        self.transformer = CondTransformer(
+            vq_cfg['embed_dim'], config.dim, self.num_tokens, config.dim_head, config.mlp_dim,
+            config.num_head, config.depth, config.dropout, context_dim, vq_cfg['n_embed'],
+        )
+        self.mask_token = nn.Parameter(torch.zeros(1, vq_cfg['embed_dim']))
+        self.mask_token_id = vq_cfg['n_embed']
+        nn.init.normal_(self.mask_token, std=.02)
+        self._pm_dtype = torch.float32
+        self._engine = None
+
+    # -- precision / engines ------------------------------------------------------------------------
+    def set_compute_dtype(self, dtype):
+        self.vqgan.set_compute_dtype(dtype)
+        for m in self.transformer.modules():
+            m._pm_dtype = dtype
+        self._pm_dtype = dtype
+        return self
+
+    @property
+    def compute_dtype(self):
+        if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+            return torch.bfloat16
+        return self._pm_dtype
+
+    def engine(self):
+        dtype = self.compute_dtype
+        cb = self.vqgan.quantize.embedding.weight
+        stamp = (packing.params_fingerprint(self.transformer), cb.data_ptr(), cb._version, self.mask_token.data_ptr(),
+                 self.mask_token._version, dtype)
+        if self._engine is None or self._engine[0] != stamp:
+            self._engine = (stamp, S2Engine(self.transformer, cb, self.mask_token, dtype))
+        return self._engine[1]
+
+    def from_pretrained(self, path):
+        return self.load_state_dict(torch.load(path, map_location="cpu"))
+
+    # -- training-only members of the reference -----------------------------------------------------
+    def forward(self, img, text=None, mask_ratio=0.75):
+        raise NotImplementedError("paintmind_amd implements the generation path only (training forward/loss: out of scope)")
+
+    # -- inference API ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def to_latent(self, img, text=None):
+        x, _, indices = self.vqgan.encode(img)
+        if exists(text):
+            text = self.text_model(text)
+        return x, indices, text
+
+    def tokens2logits(self, token, text=None):
+        return self.engine().forward(token, text)
+
+    @torch.no_grad()
+    def ids2tokens(self, ids):
+        """lookup in cat(RAW codebook, mask_token) (generate.py:148-157)."""
+        table = torch.cat((self.vqgan.quantize.embedding.weight.data.float(), self.mask_token.data.float())).contiguous()
+        rows = ops.embed_rows(table, ids.contiguous().reshape(-1), table.shape[1], torch.float32)
+        return rows.reshape(ids.shape + (table.shape[1],))
+
+    @torch.no_grad()
+    def sample(self, ids, mask_ratio, text=None, topk=1, temperature=1, noise=None, seed=0, step=0, image_base=0):
+        """One MaskGIT step (generate.py:159-181) -> (ids', img).
+
+        ``noise``: optional uniform(0,1) tensor shaped like the logits (B,N,V) -- the parity hook for the
+        reference's ``torch.zeros_like(t).uniform_(0,1)``; without it a counter-based Philox stream keyed
+        by (seed, step, image_base + image index, position, class) is used.
+        """
+        nm = num_token_masked(mask_ratio, self.num_tokens)
+        eng = self.engine()
+        ids = ids.to(eng.device, torch.int64).clone().contiguous()
+        ids, img, _, _ = eng.sample(self.vqgan.engine(), ids, text, topk, temperature, nm, noise=noise, seed=seed, step=step,
+                                    image_base=image_base, want_img=True)
+        return ids, img
+
+    def _schedule(self, timesteps, temperature):
+        temps, nmask = [], []
+        for step in range(timesteps):
+            progress = (step + 1) / timesteps
+            masked_r = mask_schedule(progress)
+            temps.append(temperature * (1 - step / timesteps))
+            nmask.append(num_token_masked(masked_r, self.num_tokens))
+        return temps, nmask
+
+    @torch.no_grad()
+    def generate(self, text, timesteps=18, temperature=1.0, topk=5, save_interval=2, seed=None, image_base=0,
+                 return_ids=False, keep_on_device=False):
+        """Full decode loop (generate.py:183-198): list of (B,3,H,W) CPU tensors for steps % save_interval == 0."""
+        B = len(text)
+        context = self.text_model(text)
+        eng = self.engine()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # governed by torch.manual_seed like the reference
+        ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
+        temps, nmask = self._schedule(timesteps, temperature)
+        flags = [step % save_interval == 0 for step in range(timesteps)]
+        ids, imgs = eng.generate(self.vqgan.engine(), ids, context, temps, nmask, flags, topk, seed=seed, image_base=image_base)
+        out = [] if imgs is None else [im if keep_on_device else im.cpu() for im in imgs]
+        return (out, ids) if return_ids else out
+
+    def _region_loop(self, img, coord, text, timesteps, topk, temperature, keep_inside):
+        z, ids, text = self.to_latent(img, text)
+        s = self.patch_size
+        x, y, h, w = coord[0] // s, coord[1] // s, coord[2] // s, coord[3] // s
+        g = self.image_size // s
+        keep = torch.zeros(g, g, dtype=torch.bool, device=ids.device) if keep_inside else \
+            torch.ones(g, g, dtype=torch.bool, device=ids.device)
+        keep[y:y + h, x:x + w] = keep_inside
+        keep = keep.reshape(1, -1)
+        # the reference builds this with float arithmetic (ids*mask + id*(1-mask), generate.py:210,229),
+        # which yields a float tensor that nn.Embedding rejects; the intended integer result is used here
+        ids = torch.where(keep, ids, torch.full_like(ids, self.mask_token_id))
+        out = None
+        for step in range(timesteps):
+            progress = (step + 1) / timesteps
+            masked_r = mask_schedule(progress)
+            cur_temp = temperature * (1 - step / timesteps)
+            ids, out = self.sample(ids, mask_ratio=masked_r, text=text, topk=topk, temperature=cur_temp, step=step)
+        return out
+
+    @torch.no_grad()
+    def inpaint(self, img, coord, text=None, timesteps=1, topk=1, temperature=0):
+        """re-generate the rectangle coord=(x,y,h,w) in pixels (generate.py:200-217)."""
+        return self._region_loop(img, coord, text, timesteps, topk, temperature, keep_inside=False)
+
+    @torch.no_grad()
+    def outpaint(self, img, coord, text=None, timesteps=1, topk=1, temperature=0):
+        """keep the rectangle, re-generate everything else (generate.py:219-236)."""
+        return self._region_loop(img, coord, text, timesteps, topk, temperature, keep_inside=True)

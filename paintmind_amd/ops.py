@@ -1,0 +1,264 @@
+"""Operator-level host wrappers: torch tensors in, torch tensors out, compute in libpaintmind_hip.so.
+
+PyTorch is plumbing here (device memory from its caching allocator, the current HIP stream).  Every
+function asserts its operands live on a ROCm device; nothing falls back to ATen.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, PART_K, PART_Q, PART_V, check
+
+_TORCH2PM = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def pm_dtype(dt):
+    try:
+        return _TORCH2PM[dt]
+    except KeyError:
+        raise TypeError(f"paintmind_amd computes in float32 or bfloat16, not {dt}") from None
+
+
+def _dev(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.PmhipError(
+                "paintmind_amd runs only on a ROCm device (got a CPU tensor); there is no CPU fallback")
+        if not t.is_contiguous():
+            raise ValueError("paintmind_amd ops need contiguous tensors")
+        dev = t.device if dev is None else dev
+        if t.device != dev:
+            raise ValueError("operands live on different devices")
+    return dev
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def swiglu_hidden(hidden_features):
+    """hidden width rule of SwiGLUFFNFused (reference modules/mlp.py:53)."""
+    return (int(hidden_features * 2 / 3) + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(a, w, bias=None, residual=None, res_rows=0, out_dtype=None):
+    """a[M,K] @ w[N,K]^T (+bias) (+residual[m % res_rows])."""
+    dev = _dev(a, w, bias, residual)
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    out_dtype = out_dtype or a.dtype
+    out = torch.empty(M, N, device=dev, dtype=out_dtype)
+    ldr = residual.shape[-1] if residual is not None else 0
+    rr = res_rows or (residual.shape[0] if residual is not None else 0)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_gemm(pm_dtype(a.dtype), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(residual), ldr,
+                             rr, _p(out), N, pm_dtype(out_dtype), M, N, K, stream_ptr(dev)), "pmhip_gemm")
+    return out
+
+
+def gemm_swiglu(a, w12p, b12p):
+    dev = _dev(a, w12p, b12p)
+    lib = _lib.load()
+    M, K = a.shape
+    Hp = w12p.shape[0] // 2
+    out = torch.empty(M, Hp, device=dev, dtype=a.dtype)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_gemm_swiglu(pm_dtype(a.dtype), _p(a), a.stride(0), _p(w12p), _p(b12p), _p(out), Hp, M, Hp, K,
+                                    stream_ptr(dev)), "pmhip_gemm_swiglu")
+    return out
+
+
+def gemm_heads(a, w, heads, tokens, kinds, q_scale=1.0):
+    """Head-split projection; returns one tensor per part (Q [B,H,t,64], K [B,H,tp,64], V^T [B,H,64,tp])."""
+    dev = _dev(a, w)
+    lib = _lib.load()
+    M, K = a.shape
+    B = M // tokens
+    tp = round_up(tokens, 64)
+    outs = []
+    for kind in kinds:
+        if kind == PART_Q:
+            outs.append(torch.empty(B, heads, tokens, 64, device=dev, dtype=a.dtype))
+        elif kind == PART_K:
+            outs.append(torch.zeros(B, heads, tp, 64, device=dev, dtype=a.dtype))
+        else:
+            outs.append(torch.zeros(B, heads, 64, tp, device=dev, dtype=a.dtype))
+    kinds_c = (C.c_int * len(kinds))(*kinds)
+    outs_c = (C.c_void_p * len(kinds))(*[o.data_ptr() for o in outs])
+    with torch.cuda.device(dev):
+        check(lib.pmhip_gemm_heads(pm_dtype(a.dtype), _p(a), a.stride(0), _p(w), w.stride(0), M, K, heads, tokens, tp,
+                                   len(kinds), kinds_c, outs_c, float(q_scale), stream_ptr(dev)), "pmhip_gemm_heads")
+    return outs
+
+
+def attention(q, k, vt, n_kv, use_exp2=False):
+    """q [B,H,Nq,64], k [B,H,Nkp,64], vt [B,H,64,Nkp] -> [B*Nq, H*64]."""
+    dev = _dev(q, k, vt)
+    lib = _lib.load()
+    B, H, Nq, _ = q.shape
+    nkp = k.shape[2]
+    out = torch.empty(B * Nq, H * 64, device=dev, dtype=q.dtype)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_attention(pm_dtype(q.dtype), _p(q), _p(k), _p(vt), _p(out), H * 64, B, H, Nq, n_kv, nkp,
+                                  int(use_exp2), stream_ptr(dev)), "pmhip_attention")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32):
+    dev = _dev(x, gamma, beta)
+    lib = _lib.load()
+    M, D = x.shape
+    out = torch.empty(M, D, device=dev, dtype=out_dtype)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_layernorm(_p(x), _p(gamma), _p(beta), float(eps), _p(out), pm_dtype(out_dtype), M, D,
+                                  stream_ptr(dev)), "pmhip_layernorm")
+    return out
+
+
+def patchify(img, patch, out_dtype=torch.float32):
+    dev = _dev(img)
+    lib = _lib.load()
+    B, Cc, H, W = img.shape
+    out = torch.empty(B * (H // patch) * (W // patch), Cc * patch * patch, device=dev, dtype=out_dtype)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_patchify(_p(img), _p(out), pm_dtype(out_dtype), B, Cc, H, W, patch, stream_ptr(dev)),
+              "pmhip_patchify")
+    return out
+
+
+def unpatchify_clamp(y, B, channels, size, patch, lo=-1.0, hi=1.0):
+    dev = _dev(y)
+    lib = _lib.load()
+    img = torch.empty(B, channels, size, size, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_unpatchify_clamp(_p(y), _p(img), B, channels, size, size, patch, float(lo), float(hi),
+                                         stream_ptr(dev)), "pmhip_unpatchify_clamp")
+    return img
+
+
+def convert_pad(x, kpad, out_dtype):
+    dev = _dev(x)
+    lib = _lib.load()
+    M, K = x.shape
+    out = torch.empty(M, kpad, device=dev, dtype=out_dtype)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_convert_pad(_p(x), K, _p(out), pm_dtype(out_dtype), kpad, M, stream_ptr(dev)),
+              "pmhip_convert_pad")
+    return out
+
+
+def add_rows(x, table):
+    dev = _dev(x, table)
+    lib = _lib.load()
+    M, D = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_add_rows(_p(x), _p(table), table.shape[0], _p(out), M, D, stream_ptr(dev)), "pmhip_add_rows")
+    return out
+
+
+def embed_rows(table, ids, kpad, out_dtype):
+    dev = _dev(table, ids)
+    lib = _lib.load()
+    V, E = table.shape
+    M = ids.numel()
+    out = torch.empty(M, kpad, device=dev, dtype=out_dtype)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_embed_rows(_p(table), _p(ids), _p(out), pm_dtype(out_dtype), kpad, M, V, E, stream_ptr(dev)),
+              "pmhip_embed_rows")
+    return out
+
+
+def vq_prepare(codebook):
+    dev = _dev(codebook)
+    lib = _lib.load()
+    V, E = codebook.shape
+    en = torch.empty_like(codebook)
+    sq = torch.empty(V, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_vq_prepare(_p(codebook), _p(en), _p(sq), V, E, stream_ptr(dev)), "pmhip_vq_prepare")
+    return en, sq
+
+
+def vq_quantize(z, en, sq, beta=0.25):
+    """z fp32 [M,E] -> (z_out [M,E], idx int64 [M], loss [1])."""
+    dev = _dev(z, en, sq)
+    lib = _lib.load()
+    M, E = z.shape
+    V = en.shape[0]
+    z_out = torch.empty_like(z)
+    idx = torch.empty(M, device=dev, dtype=torch.int64)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    scratch = torch.empty(lib.pmhip_vq_scratch_bytes(M, V), device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_vq_quantize(_p(z), _p(en), _p(sq), float(beta), _p(z_out), _p(idx), _p(loss), _p(scratch), M, V,
+                                    E, stream_ptr(dev)), "pmhip_vq_quantize")
+    return z_out, idx, loss
+
+
+def sample_rows(logits, ids, mask_id, topk, temperature, noise=None, seed=0, step=0, row_base=0):
+    """logits fp32 [M,V], ids int64 [M] -> (pred [M], merged ids [M], score [M])."""
+    dev = _dev(logits, ids, noise)
+    lib = _lib.load()
+    M, V = logits.shape
+    pred = torch.empty(M, device=dev, dtype=torch.int64)
+    ids_out = torch.empty(M, device=dev, dtype=torch.int64)
+    score = torch.empty(M, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_sample_rows(_p(logits), logits.stride(0), _p(ids), int(mask_id), int(topk), float(temperature),
+                                    _p(noise), int(seed), int(step), int(row_base), _p(pred), _p(ids_out), _p(score),
+                                    M, V, stream_ptr(dev)), "pmhip_sample_rows")
+    return pred, ids_out, score
+
+
+def remask(ids, scores, num_mask, mask_id):
+    """in place on ids int64 [B,N]."""
+    dev = _dev(ids, scores)
+    lib = _lib.load()
+    B, N = ids.shape
+    with torch.cuda.device(dev):
+        check(lib.pmhip_remask(_p(ids), _p(scores), int(num_mask), int(mask_id), B, N, stream_ptr(dev)), "pmhip_remask")
+    return ids
+
+
+# ------------------------------------------------------------------------------------------------
+def timing_enable(on=True):
+    check(_lib.load().pmhip_timing_enable(int(on)))
+
+
+def timing_reset():
+    check(_lib.load().pmhip_timing_reset())
+
+
+def timing_get(family):
+    n = C.c_int(0)
+    ms = C.c_double(0.0)
+    check(_lib.load().pmhip_timing_get(family.encode(), C.byref(n), C.byref(ms)), "pmhip_timing_get")
+    return n.value, ms.value
+
+
+def device_info(device=0):
+    cu = C.c_int(0)
+    lds = C.c_int(0)
+    arch = C.create_string_buffer(64)
+    check(_lib.load().pmhip_device_info(int(device), C.byref(cu), C.byref(lds), arch, 64), "pmhip_device_info")
+    return {"cu_count": cu.value, "lds_bytes": lds.value, "arch": arch.value.decode()}
+
+
+LOG2E = math.log2(math.e)
+__all__ = [n for n in dir() if not n.startswith("_")]

