@@ -1,0 +1,280 @@
+"""Generate the committed golden vectors by running the REFERENCE itself (imported from /root/reference,
+development container only -- see _ref_import.py).  The fixtures are data: seeded inputs and the
+reference's outputs.  Run:  python tests/golden/make_goldens.py
+
+F1  tiny_vqgan.npz / tiny_pipeline.npz : tiny configs, weights + inputs + intermediates
+F2  full_vqgan.npz / full_stage2.npz   : full-size configs; weights are NOT stored -- both sides
+    re-create them with torch.manual_seed(seed) + create_model (bit-identical init, checked by sha256)
+F3  api.json                            : API-behaviour facts (shapes, dtypes, list lengths, errors)
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import _ref_import  # noqa: E402
+from _ref_import import import_reference  # noqa: E402
+
+ref = import_reference()
+from paintmind.config import ver2cfg as ref_cfg  # noqa: E402
+from paintmind.generate import Pipeline as RefPipeline  # noqa: E402
+import paintmind.generate as ref_generate  # noqa: E402
+from paintmind_amd.config import ver2cfg as my_cfg  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+class CaptureUniform:
+    """records every tensor filled by Tensor.uniform_ while the (unmodified) reference code runs: this is
+    how the gumbel noise of generate.py:41 is captured (ids2tokens' nn.Embedding init, generate.py:153,
+    also consumes the generator, so re-seeding alone does not reproduce it)"""
+
+    def __enter__(self):
+        self.rec = []
+        self.orig = torch.Tensor.uniform_
+        outer = self
+
+        def patched(t, *a, **k):
+            r = outer.orig(t, *a, **k)
+            outer.rec.append(t.detach().clone())
+            return r
+        torch.Tensor.uniform_ = patched
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.uniform_ = self.orig
+
+
+def sd_np(module, skip=("text_model",)):
+    return {k: v.numpy().copy() for k, v in module.state_dict().items() if not k.startswith(skip)}
+
+
+def sd_sha(module, skip=("text_model",)):
+    h = hashlib.sha256()
+    for k, v in module.state_dict().items():
+        if k.startswith(skip):
+            continue
+        h.update(k.encode())
+        h.update(v.numpy().tobytes())
+    return h.hexdigest()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB, {len(arrays)} arrays")
+
+
+def tiny_vqgan():
+    ref_cfg["tiny-vqgan"] = my_cfg["tiny-vqgan"]
+    torch.manual_seed(11)
+    m = ref.create_model(arch="vqgan", version="tiny-vqgan", pretrained=False).eval()
+    # give LayerNorms / biases non-trivial values so that every parameter is exercised
+    g = torch.Generator().manual_seed(12)
+    for k, v in m.state_dict().items():
+        if k.endswith("bias"):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.05)
+        elif "norm" in k and k.endswith("weight"):
+            v.copy_(1 + torch.randn(v.shape, generator=g) * 0.1)
+    x = torch.rand(3, 3, 32, 32, generator=torch.Generator().manual_seed(13)) * 2 - 1
+    out = {"w:" + k: v for k, v in sd_np(m).items()}
+    out["x"] = x.numpy()
+    enc = m.encoder
+    h = enc.to_patch_embedding(x)
+    out["patch_embed"] = h.numpy()
+    h = enc.norm_pre(h + enc.position_embedding)
+    out["norm_pre"] = h.numpy()
+    for i, layer in enumerate(enc.transformer.layers):
+        ln = layer.norm1(h)
+        if i == 0:
+            out["l0_norm1"] = ln.numpy()
+            out["l0_attn1"] = layer.attn1(ln).numpy()
+            h1 = layer.attn1(ln) + h
+            out["l0_ffn"] = layer.ffnet(layer.norm2(h1)).numpy()
+        h = layer(h)
+        out[f"enc_layer{i}"] = h.numpy()
+    ze = m.prev_quant(h)
+    out["prev_quant"] = ze.numpy()
+    z, loss, idx = m.encode(x)
+    out["z"], out["loss"], out["idx"] = z.numpy(), loss.numpy(), idx.numpy()
+    zn = torch.nn.functional.normalize(ze, dim=-1).view(-1, 32)
+    en = torch.nn.functional.normalize(m.quantize.embedding.weight, dim=-1)
+    d = torch.sum(zn ** 2, dim=1, keepdim=True) + torch.sum(en ** 2, dim=1) - 2 * torch.einsum("bd,nd->bn", zn, en)
+    out["distances"] = d.numpy()
+    out["rec"] = m.decode(z).numpy()
+    out["dec_unclamped"] = m.decoder(m.post_quant(z)).numpy()
+    out["rec_from_idx"] = m.decode_from_indice(idx).numpy()
+    rec, loss2 = m(x)
+    assert torch.equal(rec, m.decode(z))
+    save("tiny_vqgan.npz", **out)
+    return m
+
+
+def tiny_pipeline():
+    ref_cfg["tiny-vqgan"] = my_cfg["tiny-vqgan"]
+    cfg = {k: v for k, v in my_cfg["tiny-pipeline"].items() if k not in ("text_model", "context_dim")}
+    ctx_dim = my_cfg["tiny-pipeline"]["context_dim"]
+    ref_cfg["tiny-pipeline"] = cfg
+    _ref_import.StubTextEmbedder.ctx_dim = ctx_dim
+    # the reference sizes context_proj from its t5 table (generate.py:53); patch the table entry for the tiny run
+    src_dim = {"t5-l": ctx_dim}
+    orig_init = RefPipeline.__init__
+    torch.manual_seed(21)
+    import paintmind.generate as G
+    # Build the pipeline with a 96-wide context by temporarily swapping the CondTransformer ctor argument
+    real_ct = G.CondTransformer
+
+    def ct(*a, **k):
+        a = list(a)
+        a[8] = ctx_dim          # context_dim positional slot (generate.py:65-68)
+        return real_ct(*a, **k)
+    G.CondTransformer = ct
+    try:
+        pipe = RefPipeline(ref.Config(cfg), stage1_pretrained=False).eval()
+    finally:
+        G.CondTransformer = real_ct
+    g = torch.Generator().manual_seed(22)
+    for k, v in pipe.state_dict().items():
+        if k.startswith("text_model"):
+            continue
+        if k.endswith("bias"):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.05)
+        elif "norm" in k and k.endswith("weight"):
+            v.copy_(1 + torch.randn(v.shape, generator=g) * 0.1)
+    out = {"w:" + k: v for k, v in sd_np(pipe).items()}
+    B, N, V = 3, pipe.num_tokens, 64
+    ctx = torch.randn(B, 77, ctx_dim, generator=torch.Generator().manual_seed(23))
+    out["context"] = ctx.numpy()
+    # realistic decode-loop states: every image has at least num_token_masked masked positions (as in
+    # generate(), where the count shrinks monotonically), so torch.topk's implementation-defined order
+    # among the -1e5 scores of unmasked positions (generate.py:173,177) never decides the result
+    ids0 = torch.randint(0, V, (B, N), generator=torch.Generator().manual_seed(24))
+    gm = torch.Generator().manual_seed(25)
+    for b, frac in enumerate((1.0, 0.75, 0.6)):
+        ids0[b, torch.randperm(N, generator=gm)[:int(N * frac)]] = V
+    out["ids0"] = ids0.numpy()
+    tok = pipe.ids2tokens(ids0)
+    out["tokens"] = tok.numpy()
+    out["logits_ctx"] = pipe.tokens2logits(tok, ctx).numpy()
+    out["logits_noctx"] = pipe.tokens2logits(tok, None).numpy()
+    # one sample step: topk=1 (deterministic) and topk=5 with the exact noise the reference draws
+    for tag, text in (("ctx", ctx), ("noctx", None)):
+        ids1, img1 = pipe.sample(ids0.clone(), np.float64(0.5), text=text, topk=1, temperature=1.0)
+        out[f"s1_{tag}_ids"], out[f"s1_{tag}_img"] = ids1.numpy(), img1.numpy()
+        torch.manual_seed(31)
+        with CaptureUniform() as cap:
+            ids5, img5 = pipe.sample(ids0.clone(), np.float64(0.5), text=text, topk=5, temperature=0.7)
+        (noise,) = [t for t in cap.rec if t.shape == (B, N, V)]
+        out[f"s5_{tag}_noise"], out[f"s5_{tag}_ids"], out[f"s5_{tag}_img"] = noise.numpy(), ids5.numpy(), img5.numpy()
+    # a chained 4-step decode loop driven exactly like generate() (generate.py:189-196), with the noise captured
+    T, topk, temperature = 4, 3, 1.0
+    torch.manual_seed(41)
+    ids = torch.full((B, N), V, dtype=torch.long)
+    for step in range(T):
+        masked_r = ref_generate.mask_schedule((step + 1) / T)
+        cur_temp = temperature * (1 - step / T)
+        with CaptureUniform() as cap:
+            ids, img = pipe.sample(ids, mask_ratio=masked_r, text=ctx, topk=topk, temperature=cur_temp)
+        (noise,) = [t for t in cap.rec if t.shape == (B, N, V)]
+        out[f"loop_noise{step}"], out[f"loop_ids{step}"] = noise.numpy(), ids.numpy()
+    out["loop_img_last"] = img.numpy()
+    save("tiny_pipeline.npz", **out)
+    # F3 API facts
+    imgs = pipe.generate(["a", "b"], timesteps=8, temperature=1.0, topk=5, save_interval=2)
+    api = {"generate_T8_si2_len": len(imgs), "generate_img_shape": list(imgs[0].shape), "generate_img_device": str(imgs[0].device),
+           "generate_img_dtype": str(imgs[0].dtype)}
+    ids_end = torch.full((2, N), V, dtype=torch.long)
+    ctx2 = pipe.text_model(["a", "b"])
+    nm = []
+    for step in range(8):
+        r = ref_generate.mask_schedule((step + 1) / 8)
+        nm.append(max(int((r * 1024).item()), 1))
+        ids_end, _ = pipe.sample(ids_end, r, text=ctx2, topk=5, temperature=1.0 * (1 - step / 8))
+    api["mask_counts_T8_N1024"] = nm
+    api["residual_mask_tokens_after_T8"] = int((ids_end == V).sum(1).min())
+    try:
+        ref.create_model(arch="nope", version="vit-s-vqgan", pretrained=False)
+    except ValueError as e:
+        api["bad_arch_error"] = str(e)
+    try:
+        pipe.inpaint(torch.rand(1, 3, 32, 32) * 2 - 1, (8, 8, 16, 16))
+        api["inpaint_runs"] = True
+    except Exception as e:  # the reference's float-ids quirk (generate.py:210)
+        api["inpaint_runs"] = False
+        api["inpaint_error_type"] = type(e).__name__
+    return api
+
+
+def full_vqgan():
+    torch.manual_seed(0)
+    m = ref.create_model(arch="vqgan", version="vit-s-vqgan", pretrained=False).eval()
+    sha = sd_sha(m)
+    x = torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(100)) * 2 - 1
+    z, loss, idx = m.encode(x)
+    ze = m.prev_quant(m.encoder(x))
+    zn = torch.nn.functional.normalize(ze, dim=-1).view(-1, 32)
+    en = torch.nn.functional.normalize(m.quantize.embedding.weight, dim=-1)
+    d = torch.sum(zn ** 2, dim=1, keepdim=True) + torch.sum(en ** 2, dim=1) - 2 * torch.einsum("bd,nd->bn", zn, en)
+    top2 = torch.topk(d, 2, dim=1, largest=False).values
+    rec = m.decode(z)
+    save("full_vqgan.npz", idx=idx.numpy().astype(np.int16), gap=(top2[:, 1] - top2[:, 0]).numpy(), z=z.numpy(),
+         prev_quant=ze.numpy(), loss=loss.numpy(), rec_sub=rec[:, :, ::4, ::4].numpy(),
+         rec_sha=np.frombuffer(hashlib.sha256(rec.numpy().tobytes()).digest(), dtype=np.uint8),
+         rec_clamped_frac=np.array((rec.abs() == 1).float().mean().item(), dtype=np.float32),
+         weights_sha=np.frombuffer(bytes.fromhex(sha), dtype=np.uint8))
+    return {"full_vqgan_weights_sha256": sha}
+
+
+def full_stage2():
+    """BASELINE cfg 3: vit-s-vqgan + 12L/d512, context=None, one sample step at B=1, topk=1."""
+    cfg = {k: v for k, v in my_cfg["bench-uncond-12L-d512"].items() if k not in ("text_model", "context_dim")}
+    ref_cfg["bench-uncond-12L-d512"] = cfg
+    import paintmind.generate as G
+    real_ct = G.CondTransformer
+
+    def ct(*a, **k):
+        a = list(a)
+        a[8] = 512
+        return real_ct(*a, **k)
+    G.CondTransformer = ct
+    try:
+        torch.manual_seed(0)
+        pipe = RefPipeline(ref.Config(cfg), stage1_pretrained=False).eval()
+    finally:
+        G.CondTransformer = real_ct
+    sha = sd_sha(pipe)
+    N, V = 1024, 8192
+    ids0 = torch.randint(0, V, (1, N), generator=torch.Generator().manual_seed(200))
+    ids0[0, torch.rand(N, generator=torch.Generator().manual_seed(201)) < 0.6] = V
+    logits = pipe.tokens2logits(pipe.ids2tokens(ids0), None)
+    ids1, img1 = pipe.sample(ids0.clone(), np.float64(0.4), text=None, topk=1, temperature=1.0)
+    lse = torch.logsumexp(logits, -1)
+    top2 = torch.topk(logits, 2, dim=-1).values
+    save("full_stage2.npz", ids0=ids0.numpy().astype(np.int16), logits_sub=logits[:, ::8, ::64].numpy(),
+         logits_argmax=logits.argmax(-1).numpy().astype(np.int16), logits_lse=lse.numpy(),
+         logits_top2gap=(top2[..., 0] - top2[..., 1]).numpy(), ids1=ids1.numpy().astype(np.int16),
+         img1_sub=img1[:, :, ::4, ::4].numpy(), weights_sha=np.frombuffer(bytes.fromhex(sha), dtype=np.uint8))
+    return {"full_stage2_weights_sha256": sha}
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["tiny_vqgan", "tiny_pipeline", "full_vqgan", "full_stage2"]
+    api_path = os.path.join(HERE, "api.json")
+    api = json.load(open(api_path)) if os.path.exists(api_path) else {}
+    api["torch_version"] = torch.__version__
+    if "tiny_vqgan" in which:
+        tiny_vqgan()
+    if "tiny_pipeline" in which:
+        api.update(tiny_pipeline())
+    if "full_vqgan" in which:
+        api.update(full_vqgan())
+    if "full_stage2" in which:
+        api.update(full_stage2())
+    json.dump(api, open(api_path, "w"), indent=2, sort_keys=True)
+    print(json.dumps(api, indent=2, sort_keys=True))

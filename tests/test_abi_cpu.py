@@ -1,0 +1,98 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every declared symbol, and the
+host API mirrors the reference's surface.  No compute calls (there is no GPU here)."""
+import os
+import re
+
+import pytest
+import torch
+
+import paintmind_amd as pm
+from paintmind_amd import _lib
+from util import ROOT, api_facts
+
+
+def test_header_and_prototypes_agree():
+    hdr = open(os.path.join(ROOT, "include", "pmhip.h")).read()
+    declared = set(re.findall(r"\b(pmhip_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"pmhip_stream"}
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+
+
+def test_library_exports_every_symbol():
+    lib = _lib.load()                      # binds every prototype, raises on a missing symbol
+    assert lib.pmhip_abi_version() == _lib.ABI_VERSION
+    assert lib.pmhip_vq_scratch_bytes(1024, 8192) >= 4 * 1024 * 8
+
+
+def test_errors_are_reported_not_thrown():
+    import ctypes as C
+    lib = _lib.load()
+    rc = lib.pmhip_gemm(0, None, 64, None, 64, None, None, 0, 0, None, 64, 0, 128, 128, 64, None)
+    assert rc == 1 and b"null" in lib.pmhip_last_error()
+    rc = lib.pmhip_gemm(0, C.c_void_p(8), 64, C.c_void_p(8), 64, None, None, 0, 0, C.c_void_p(8), 64, 0, 128, 128, 60, None)
+    assert rc == 1 and b"multiple of 64" in lib.pmhip_last_error()
+    rc = lib.pmhip_timing_get(b"nope", None, None)
+    assert rc == 1
+
+
+def test_no_cpu_fallback():
+    torch.manual_seed(0)
+    m = pm.create_model(arch="vqgan", version="tiny-vqgan", pretrained=False)
+    with pytest.raises(_lib.PmhipError):
+        m.encode(torch.zeros(1, 3, 32, 32))
+    from paintmind_amd import ops
+    with pytest.raises(_lib.PmhipError):
+        ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64))
+
+
+def test_factory_surface():
+    with pytest.raises(ValueError) as e:
+        pm.create_model(arch="nope", version="vit-s-vqgan", pretrained=False)
+    assert str(e.value) == api_facts()["bad_arch_error"]
+    cfg = pm.Config(pm.ver2cfg["vit-s-vqgan"])
+    assert cfg.enc["dim"] == 512 and cfg.to_dict()["n_embed"] == 8192
+    c2 = pm.Config()
+    c2.from_dict({"a": 1})
+    assert c2.a == 1 and "a" in repr(c2)
+
+
+def test_seeded_weights_match_reference_checksum():
+    """torch.manual_seed(0) + create_model reproduces the reference's random init bit-for-bit (sha256 of the
+    state_dict recorded by make_goldens.py from the reference)."""
+    import hashlib
+    torch.manual_seed(0)
+    m = pm.create_model(arch="vqgan", version="vit-s-vqgan", pretrained=False)
+    h = hashlib.sha256()
+    for k, v in m.state_dict().items():
+        h.update(k.encode())
+        h.update(v.numpy().tobytes())
+    assert h.hexdigest() == api_facts()["full_vqgan_weights_sha256"]
+    assert sum(p.numel() for p in m.parameters()) == 52032992
+
+
+def test_pipeline_wiring_and_schedule():
+    from paintmind_amd.generate import Pipeline, num_token_masked, mask_schedule
+    torch.manual_seed(0)
+    p = Pipeline(pm.Config(pm.ver2cfg["tiny-pipeline"]), stage1_pretrained=False)
+    assert p.num_tokens == 16 and p.mask_token_id == 64 and p.mask_token.shape == (1, 32)
+    keys = [k for k in p.state_dict() if not k.startswith("text_model")]
+    assert "transformer.layers.layer0.attn2.to_k.weight" in keys and "vqgan.quantize.embedding.weight" in keys
+    nm = [num_token_masked(mask_schedule((s + 1) / 8), 1024) for s in range(8)]
+    assert nm == api_facts()["mask_counts_T8_N1024"]
+    temps, nmask = p._schedule(8, 1.0)
+    assert temps[0] == 1.0 and temps[-1] == 0.125 and nmask[-1] == 1
+    with pytest.raises(NotImplementedError):
+        p(torch.zeros(1, 3, 32, 32))
+
+
+def test_packing_roundtrip():
+    """interleaved SwiGLU packing: rows [16 x1 | 16 x2] and zero padding to a multiple of 64."""
+    from paintmind_amd import packing
+    lin = torch.nn.Linear(64, 2 * 88)
+    w12p, b12p, hp = packing.pack_w12(lin, torch.float32)
+    assert hp == 128 and w12p.shape == (256, 64)
+    w = lin.weight.detach()
+    assert torch.equal(w12p[0:16], w[0:16]) and torch.equal(w12p[16:32], w[88:104])
+    assert torch.equal(w12p[32:48], w[16:32]) and torch.equal(w12p[160 + 16:160 + 24], w[88 + 80:88 + 88])
+    assert torch.count_nonzero(w12p[160 + 8:160 + 16]) == 0 and torch.count_nonzero(w12p[192:]) == 0
+    assert torch.equal(b12p[16:32], lin.bias.detach()[88:104])
