@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 256x256 images/sec/GPU, 8-step MaskGIT decode with vit-s-vqgan tokens.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over one batch of synthetic input that is already resident
+in HBM: for the default workload (BASELINE.json configs[2]) that is ONE Pipeline.generate() of B=64
+images -- 8 MaskGIT steps of the 12-layer d=512 transformer (context=None, so attn2 is a second
+self-attention) plus a ViT decode of the sampled tokens after EVERY step, which is the work the
+reference does per generate() (generate.py:165; nothing is skipped).  Images stay on the device.
+Multi-GPU: weak scaling, every rank decodes its own 64 images (RNG keyed by global image index), no
+collective in the data path, one RCCL gather of the finished images to rank 0 inside the timed region.
+
+One JSON line is printed by rank 0; see DESIGN.md for how `roofline` and `cpu_baseline` are derived.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import paintmind_amd as pm  # noqa: E402
+from paintmind_amd import ops  # noqa: E402
+from paintmind_amd.config import ver2cfg  # noqa: E402
+from paintmind_amd.generate import Pipeline  # noqa: E402
+from paintmind_amd.ops import swiglu_hidden  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md chip table
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (pipeline config, batch per GPU, timesteps, context length or None)
+    "maskgit-uncond-12L-d512-T8": ("bench-uncond-12L-d512", 64, 8, None),      # BASELINE configs[2]
+    "maskgit-text-24L-d768-T8": ("bench-text-24L-d768", 32, 8, 77),            # north_star target model, 8 steps
+    "maskgit-text-24L-d768-T12": ("bench-text-24L-d768", 32, 12, 77),          # BASELINE configs[3] per-GPU share
+    "vit-s-recon": (None, 64, 0, None),                                         # BASELINE configs[1]
+}
+
+
+# ---------------------------------------------------------------------------------------------
+# algorithmic work (2*M*N*K per GEMM, 4*N*Nkv*inner per attention core)
+# ---------------------------------------------------------------------------------------------
+def layer_flops(D, heads, mlp_dim, N, stage2, ctx_len):
+    inner, hf = heads * 64, swiglu_hidden(mlp_dim)
+    proj_self = 4 * 2 * N * D * inner
+    core_self = 4 * N * N * inner
+    gemm, attn = proj_self, core_self
+    if stage2:
+        if ctx_len is None:
+            gemm += proj_self
+            attn += core_self
+        else:
+            gemm += 2 * 2 * N * D * inner + 2 * 2 * ctx_len * D * inner
+            attn += 4 * N * ctx_len * inner
+    gemm += 6 * N * D * hf
+    return gemm, attn
+
+
+def vit_flops(tower, embed_dim, patch_k, encode):
+    N = (tower["image_size"] // tower["patch_size"]) ** 2
+    g, a = layer_flops(tower["dim"], tower["num_head"], tower["mlp_dim"], N, False, None)
+    gemm, attn = g * tower["depth"], a * tower["depth"]
+    gemm += 2 * N * patch_k * tower["dim"] + 2 * N * tower["dim"] * embed_dim
+    if encode:
+        gemm += 2 * N * embed_dim * 8192          # the VQ distance product (quantize.py:26)
+    return gemm, attn
+
+
+def s2_step_flops(cfg, N, embed_dim, n_embed, ctx_len):
+    g, a = layer_flops(cfg["dim"], cfg["num_head"], cfg["mlp_dim"], N, True, ctx_len)
+    gemm, attn = g * cfg["depth"], a * cfg["depth"]
+    gemm += 2 * N * embed_dim * cfg["dim"] + 2 * N * cfg["dim"] * n_embed
+    return gemm, attn
+
+
+# ---------------------------------------------------------------------------------------------
+def build(workload, device, dtype):
+    cfg_name, B, T, L = WORKLOADS[workload]
+    torch.manual_seed(0)
+    if cfg_name is None:
+        model = pm.create_model(arch="vqgan", version="vit-s-vqgan", pretrained=False).to(device).eval()
+        model.set_compute_dtype(dtype)
+        return model, None
+    pipe = Pipeline(pm.Config(ver2cfg[cfg_name]), stage1_pretrained=False).to(device).eval()
+    pipe.set_compute_dtype(dtype)
+    return pipe, ver2cfg[cfg_name]
+
+
+def make_step(workload, model, device, rank, decode_every_step=True):
+    cfg_name, B, T, L = WORKLOADS[workload]
+    if cfg_name is None:
+        x = (torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(rank)) * 2 - 1).to(device)
+
+        def step(i):
+            z, _, _ = model.encode(x)
+            return model.decode(z)
+        return step
+    pipe = model
+    eng, vq_eng = pipe.engine(), pipe.vqgan.engine()
+    ctx = None
+    if L is not None:
+        g = torch.Generator().manual_seed(1234 + rank)
+        ctx = torch.randn(B, L, ver2cfg[cfg_name]["context_dim"], generator=g).to(device)
+    temps, nmask = pipe._schedule(T, 1.0)
+    flags = [True] * T if decode_every_step else [t == T - 1 for t in range(T)]
+
+    def step(i):
+        ids = torch.full((B, pipe.num_tokens), pipe.mask_token_id, dtype=torch.long, device=device)
+        ids, imgs = eng.generate(vq_eng, ids, ctx, temps, nmask, flags, topk=5, seed=1000 + i, image_base=rank * B)
+        return imgs[-1]
+    return step
+
+
+def work_per_step(workload):
+    """(gemm flops, attention flops, sampled logits bytes) of one bench step on one GPU"""
+    cfg_name, B, T, L = WORKLOADS[workload]
+    vq = ver2cfg["vit-s-vqgan"]
+    pk = 3 * vq["enc"]["patch_size"] ** 2
+    if cfg_name is None:
+        ge, ae = vit_flops(vq["enc"], vq["embed_dim"], pk, True)
+        gd, ad = vit_flops(vq["dec"], vq["embed_dim"], pk, False)
+        return B * (ge + gd), B * (ae + ad), 0
+    cfg = ver2cfg[cfg_name]
+    gs, as_ = s2_step_flops(cfg, 1024, vq["embed_dim"], vq["n_embed"], L)
+    gd, ad = vit_flops(vq["dec"], vq["embed_dim"], pk, False)
+    return B * T * (gs + gd), B * T * (as_ + ad), B * T * 1024 * vq["n_embed"] * 4
+
+
+def cpu_baseline(workload):
+    """oracle/torch_port.py -- a functional port of the reference's torch-CPU path -- timed on this host's
+    cores on a bounded sample of the same workload (fp32, B=1)."""
+    from oracle import torch_port as TP
+    cfg_name, B, T, L = WORKLOADS[workload]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    vq = ver2cfg["vit-s-vqgan"]
+    with torch.no_grad():
+        if cfg_name is None:
+            m = pm.create_model(arch="vqgan", version="vit-s-vqgan", pretrained=False)
+            p = {k: v.detach() for k, v in m.state_dict().items()}
+            x = torch.rand(1, 3, 256, 256) * 2 - 1
+            TP.vqgan_decode(TP.vqgan_encode(x, p, vq)[0], p, vq)            # warm-up
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                TP.vqgan_decode(TP.vqgan_encode(x, p, vq)[0], p, vq)
+            dt = (time.perf_counter() - t0) / reps
+            return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+                    "sample": f"{reps} x (encode+decode) of one 256x256 image, torch-CPU fp32 port of the reference, B=1"}
+        pipe = Pipeline(pm.Config(ver2cfg[cfg_name]), stage1_pretrained=False)
+        p = {k: v.detach() for k, v in pipe.state_dict().items() if not k.startswith("text_model")}
+        ids = torch.full((1, 1024), vq["n_embed"], dtype=torch.long)
+        ctx = None if L is None else torch.randn(1, L, ver2cfg[cfg_name]["context_dim"])
+        TP.sample_step(ids, 0.9, ctx, 5, 1.0, torch.rand(1, 1024, vq["n_embed"]), p, vq, ver2cfg[cfg_name])   # warm-up
+        t0 = time.perf_counter()
+        for step in range(T):
+            noise = torch.rand(1, 1024, vq["n_embed"])
+            ids, _, _ = TP.sample_step(ids, TP.mask_schedule((step + 1) / T), ctx, 5, 1.0 * (1 - step / T), noise, p, vq,
+                                       ver2cfg[cfg_name])
+        dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"one full {T}-step generate of ONE image (B=1, every step with its ViT decode), torch-CPU fp32 port "
+                      f"of the reference on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="maskgit-uncond-12L-d512-T8", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--final-decode-only", action="store_true", help="decode only the last step's image (not the headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a {args.gpus}-rank launch (torch.distributed.run), WORLD_SIZE={world}")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model, _ = build(args.workload, device, dtype)
+    step = make_step(args.workload, model, device, rank, decode_every_step=not args.final_decode_only)
+    B = WORKLOADS[args.workload][1]
+
+    def gather(last):
+        if dist is None:
+            return last
+        bufs = [torch.empty_like(last) for _ in range(world)] if rank == 0 else None
+        dist.gather(last, bufs, dst=0)
+        return last
+
+    for i in range(args.warmup):
+        gather(step(i))
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        gather(step(args.warmup + i))
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    result = {
+        "metric": "256x256 images/sec, 8-step MaskGIT decode (vit-s-vqgan), whole job", "value": round(value, 3),
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic (seeded random-init weights, all-masked start ids, Philox sampling noise)",
+        "config": {"workload": args.workload, "batch_per_gpu": B, "timesteps": WORKLOADS[args.workload][2],
+                   "topk": 5, "decode": "final step only" if args.final_decode_only else "every step (reference-equivalent work)",
+                   "parallelism": f"dp{world} (independent images, no data-path collective)"},
+        "images_per_s_per_gpu": round(value / world, 3),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # per-family kernel time of ONE more step, bracketed by hipEvents on the launch stream
+        gf, af, sample_bytes = work_per_step(args.workload)
+        if args.final_decode_only and WORKLOADS[args.workload][0] is not None:
+            T = WORKLOADS[args.workload][2]
+            vq = ver2cfg["vit-s-vqgan"]
+            gd, ad = vit_flops(vq["dec"], vq["embed_dim"], 192, False)
+            gf -= B * (T - 1) * gd
+            af -= B * (T - 1) * ad
+        ops.timing_reset()
+        ops.timing_enable(True)
+        step(10_000)
+        torch.cuda.synchronize(device)
+        ops.timing_enable(False)
+        fam = {f: ops.timing_get(f) for f in ("gemm", "attention", "layernorm", "sample", "vq", "rowops")}
+        n_g, ms_g = fam["gemm"]
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        ach = gf / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
+        result["roofline"] = {
+            "kernel": "gemm_nt_kernel (all GEMM launches of one step)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launches": n_g,
+            "avg_launch_ms": round(ms_g / max(n_g, 1), 4), "algorithmic_gflop_per_launch": round(gf / max(n_g, 1) / 1e9, 2)}
+        n_a, ms_a = fam["attention"]
+        n_s, ms_s = fam["sample"]
+        result["kernel_families"] = {
+            f: {"launches": fam[f][0], "ms": round(fam[f][1], 3)} for f in fam}
+        if ms_a > 0:
+            result["kernel_families"]["attention"]["tflops"] = round(af / (ms_a * 1e-3) / 1e12, 2)
+        if ms_s > 0 and sample_bytes:
+            result["kernel_families"]["sample"]["logits_GBps"] = round(sample_bytes / (ms_s * 1e-3) / 1e9, 1)
+        result["end_to_end_tflops_per_gpu"] = round((gf + af) / (ms_per_step * 1e-3) / 1e12, 2)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.workload)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

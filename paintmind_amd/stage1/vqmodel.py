@@ -31,7 +31,7 @@ class VQModel(nn.Module):
 
     @property
     def compute_dtype(self):
-        if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+        if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16:
             return torch.bfloat16        # `with torch.autocast('cuda', torch.bfloat16)` selects perf mode
         return self._pm_dtype
 

@@ -140,3 +140,22 @@ def test_philox_reference_vector():
     assert [int(v) for v in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     u = O.philox_uniform(5, 3, np.arange(1000), np.arange(1000) % 64)
     assert u.min() >= 0 and u.max() < 1 and abs(float(u.mean()) - 0.5) < 0.05
+
+
+def test_torch_port_matches_goldens(tv, tp):
+    """oracle/torch_port.py (what bench.py times as cpu_baseline) against the same reference vectors."""
+    import torch
+    from oracle import torch_port as TP
+    p, d = tv
+    pt = {k: torch.from_numpy(v) for k, v in p.items()}
+    cfg = vq_cfg("tiny-vqgan")
+    with torch.no_grad():
+        z, loss, idx = TP.vqgan_encode(torch.from_numpy(d["x"]), pt, cfg)
+        assert np.array_equal(idx.numpy(), d["idx"]) and maxabs(z.numpy(), d["z"]) < 1e-6
+        assert maxabs(TP.vqgan_decode(torch.from_numpy(d["z"]), pt, cfg).numpy(), d["rec"]) < 5e-5
+        p2, d2 = tp
+        pt2 = {k: torch.from_numpy(v) for k, v in p2.items()}
+        ids, img, logits = TP.sample_step(torch.from_numpy(d2["ids0"]), 0.5, torch.from_numpy(d2["context"]), 5, 0.7,
+                                          torch.from_numpy(d2["s5_ctx_noise"]), pt2, cfg, s2_cfg("tiny-pipeline"))
+        assert maxabs(logits.numpy(), d2["logits_ctx"]) < 5e-5
+        assert np.array_equal(ids.numpy(), d2["s5_ctx_ids"]) and maxabs(img.numpy(), d2["s5_ctx_img"]) < 5e-5
