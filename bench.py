@@ -136,13 +136,35 @@ def work_per_step(workload):
     return B * T * (gs + gd), B * T * (as_ + ad), B * T * 1024 * vq["n_embed"] * 4
 
 
+def usable_cores():
+    """threads this process may actually run on: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / period)))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(workload):
     """oracle/torch_port.py -- a functional port of the reference's torch-CPU path -- timed on this host's
     cores on a bounded sample of the same workload (fp32, B=1)."""
     from oracle import torch_port as TP
     cfg_name, B, T, L = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
     torch.manual_seed(0)
     vq = ver2cfg["vit-s-vqgan"]
     with torch.no_grad():
@@ -200,6 +222,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    log(f"building {args.workload} ({args.dtype}) on rank {rank}/{world}")
     model, _ = build(args.workload, device, dtype)
     step = make_step(args.workload, model, device, rank, decode_every_step=not args.final_decode_only)
     B = WORKLOADS[args.workload][1]
@@ -211,8 +234,10 @@ def main():
         dist.gather(last, bufs, dst=0)
         return last
 
+    log("warm-up")
     for i in range(args.warmup):
         gather(step(i))
+    log("timed region")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -241,6 +266,7 @@ def main():
         "images_per_s_per_gpu": round(value / world, 3),
     }
 
+    log(f"timed region done: {ms_per_step:.1f} ms/step")
     if rank == 0 and not args.no_roofline:
         # per-family kernel time of ONE more step, bracketed by hipEvents on the launch stream
         gf, af, sample_bytes = work_per_step(args.workload)
