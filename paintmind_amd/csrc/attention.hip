@@ -2,9 +2,11 @@
 // Replaces the reference's materialised-score attention (modules/attention.py:51-58: q@k^T ->
 // softmax -> @v, a (B*H, N, N) fp32 tensor per layer) and its xformers alternative (:100).
 //
-// Work split: one workgroup = 128 queries of one (batch, head); 4 waves x 32 queries.  K/V stream
-// through LDS in tiles of 64 keys, prefetched into registers while the previous tile is being
-// multiplied (issue-early / write-late staging).
+// Work split: one workgroup = 256 queries (bf16; 128 in f32) of one (batch, head); 4 waves x 64 queries, so
+// every K / V^T fragment read from LDS feeds 4 MFMAs.  K/V stream through a 2-stage LDS ring in tiles of
+// 64 keys: tile t+1 is written (from registers loaded one iteration earlier) while tile t is being
+// multiplied, one barrier per tile.  In exp2 mode the running max is only raised (and O rescaled) when it
+// grows by more than 2^8 (deferred rescale; P stays <= 256, l and O accumulate in fp32).
 //
 // MFMA formulation (16x16 tiles; operand chunk = 16 B per lane, see common.h Mma<T>):
 //   S^T[key, query]  = K . Q^T     -> each lane holds ONE query column (lane&15) and 4 keys per tile,
@@ -18,7 +20,6 @@
 
 namespace {
 
-constexpr int QB = 128;       // queries per workgroup
 constexpr int KT = 64;        // keys per tile
 constexpr int DH = 64;
 constexpr int THREADS = 256;
@@ -53,13 +54,12 @@ __device__ __forceinline__ uint4 lds_chunk(const unsigned char* tile, int row, i
 // zero the elements of a 16-B V^T chunk whose key index is >= nkv (first key of the chunk = k0)
 template <typename T> __device__ __forceinline__ uint4 mask_keys(uint4 v, int k0, int nkv);
 template <> __device__ __forceinline__ uint4 mask_keys<bf16_t>(uint4 v, int k0, int nkv) {
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (k0 + 2 * i >= nkv) w[i] = 0u;
-        else if (k0 + 2 * i + 1 >= nkv) w[i] &= 0xffffu;
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    const int n = nkv - k0;                      // number of valid keys in this 8-key chunk (may be <= 0)
+    v.x = n <= 0 ? 0u : (n == 1 ? (v.x & 0xffffu) : v.x);
+    v.y = n <= 2 ? 0u : (n == 3 ? (v.y & 0xffffu) : v.y);
+    v.z = n <= 4 ? 0u : (n == 5 ? (v.z & 0xffffu) : v.z);
+    v.w = n <= 6 ? 0u : (n == 7 ? (v.w & 0xffffu) : v.w);
+    return v;
 }
 template <> __device__ __forceinline__ uint4 mask_keys<float>(uint4 v, int k0, int nkv) {
     if (k0 + 0 >= nkv) v.x = 0u;
@@ -75,15 +75,49 @@ template <> __device__ __forceinline__ uint4 pack_p<bf16_t>(const f32x4_t& lo, c
                       pack_bf16x2(hi[2], hi[3]));
 }
 
-template <typename T, bool EXP2>
-__global__ __launch_bounds__(THREADS) void attention_kernel(const T* __restrict__ Q, const T* __restrict__ Kp,
+// One K tile + one V^T tile (64 rows x ROWB bytes each) go global -> LDS by DMA, 1 KiB per wave-instruction.
+// The LDS image is lane-linear, so the bank swizzle (slot ^ row) is applied to the SOURCE address here and
+// again in lds_chunk() on the read side.
+template <typename T>
+__device__ __forceinline__ void stage_tiles(unsigned char* stage, const unsigned char* __restrict__ Kbh,
+                                            const unsigned char* __restrict__ Vbh, size_t v_row_bytes, int t, int wave,
+                                            int lane) {
+    using C = AttnCfg<T>;
+    constexpr int RPC = 1024 / C::ROWB;                  // rows per 1 KiB chunk
+    constexpr int CHUNKS = KT / RPC;                     // chunks per tile
+    constexpr int PER_WAVE = CHUNKS / 4;
+    const int kv0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int chunk = wave * PER_WAVE + i;
+        const int row = chunk * RPC + lane / C::SLOTS;
+        const int lslot = (lane % C::SLOTS) ^ (row & (C::SLOTS - 1));
+        glds16(Kbh + (size_t)(kv0 + row) * C::ROWB + lslot * 16, stage + chunk * 1024);
+        glds16(Vbh + (size_t)row * v_row_bytes + (size_t)kv0 * sizeof(T) + lslot * 16, stage + KT * C::ROWB + chunk * 1024);
+    }
+}
+
+// ragged last tile: zero the V^T columns of keys >= Nkv (K needs nothing: those scores are masked to -inf)
+template <typename T>
+__device__ __forceinline__ void zero_ragged_v(unsigned char* Vl, int kv0, int Nkv, int tid) {
+    using C = AttnCfg<T>;
+    for (int idx = tid; idx < KT * C::SLOTS; idx += THREADS) {
+        const int row = idx / C::SLOTS, lslot = idx % C::SLOTS;
+        uint4* p = reinterpret_cast<uint4*>(Vl + row * C::ROWB + ((lslot ^ (row & (C::SLOTS - 1))) << 4));
+        *p = mask_keys<T>(*p, kv0 + lslot * (16 / (int)sizeof(T)), Nkv);
+    }
+}
+
+// QF = 16-query tiles per wave (bf16: 4 -> 64 queries per wave, 256 per workgroup; f32: 2).
+template <typename T, bool EXP2, int QF>
+__global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restrict__ Q, const T* __restrict__ Kp,
                                                             const T* __restrict__ Vt, T* __restrict__ out,
                                                             int ldo, int heads, int Nq, int Nkv, int Nkv_pad) {
     using C = AttnCfg<T>;
     constexpr int TILE_BYTES = KT * C::ROWB;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
-    unsigned char* Kl = lds;
-    unsigned char* Vl = lds + TILE_BYTES;
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;              // K tile + V^T tile
+    constexpr float kDefer = EXP2 ? 8.0f : 0.0f;             // skip the O rescale while the row max grows < 2^8
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -91,7 +125,7 @@ __global__ __launch_bounds__(THREADS) void attention_kernel(const T* __restrict_
     const int l15 = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y;
     const int b = bh / heads, h = bh % heads;
-    const int q0 = blockIdx.x * QB + wave * 32;
+    const int q0 = blockIdx.x * (4 * QF * 16) + wave * (QF * 16);
 
     const T* Qbh = Q + (size_t)bh * Nq * DH;
     const unsigned char* Kbh = reinterpret_cast<const unsigned char*>(Kp + (size_t)bh * Nkv_pad * DH);
@@ -99,9 +133,9 @@ __global__ __launch_bounds__(THREADS) void attention_kernel(const T* __restrict_
     const size_t v_row_bytes = (size_t)Nkv_pad * sizeof(T);
 
     // Q fragments stay in registers for the whole kernel (column operand of S^T)
-    uint4 qreg[2][C::NCH];
+    uint4 qreg[QF][C::NCH];
 #pragma unroll
-    for (int qf = 0; qf < 2; ++qf) {
+    for (int qf = 0; qf < QF; ++qf) {
         int q = q0 + qf * 16 + l15;
         q = q < Nq ? q : Nq - 1;
         const unsigned char* qrow = reinterpret_cast<const unsigned char*>(Qbh + (size_t)q * DH);
@@ -109,148 +143,145 @@ __global__ __launch_bounds__(THREADS) void attention_kernel(const T* __restrict_
         for (int c = 0; c < C::NCH; ++c) qreg[qf][c] = *reinterpret_cast<const uint4*>(qrow + (c * 4 + g) * 16);
     }
 
-    f32x4_t o[4][2];
+    f32x4_t o[4][QF];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) o[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float mrun[2] = {-INFINITY, -INFINITY};
-    float lrun[2] = {0.f, 0.f};           // per-lane partial row sums (reduced over the 4 lane groups at the end)
+        for (int j = 0; j < QF; ++j) o[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float mrun[QF], lrun[QF];            // running max; per-lane partial row sums (reduced at the end)
+#pragma unroll
+    for (int j = 0; j < QF; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; }
 
     const int ntiles = (Nkv + KT - 1) / KT;
-    uint4 kst[C::PASSES], vst[C::PASSES];
-
-    auto issue_loads = [&](int t) {
-        const int kv0 = t * KT;
-#pragma unroll
-        for (int ps = 0; ps < C::PASSES; ++ps) {
-            const int idx = ps * THREADS + tid;
-            const int row = idx / C::SLOTS, slot = idx % C::SLOTS;
-            kst[ps] = *reinterpret_cast<const uint4*>(Kbh + (size_t)(kv0 + row) * C::ROWB + slot * 16);
-            vst[ps] = *reinterpret_cast<const uint4*>(Vbh + (size_t)row * v_row_bytes + (size_t)kv0 * sizeof(T) + slot * 16);
-        }
-    };
-    auto write_lds = [&](int t) {
-        const int kv0 = t * KT;
-        const bool ragged = kv0 + KT > Nkv;
-#pragma unroll
-        for (int ps = 0; ps < C::PASSES; ++ps) {
-            const int idx = ps * THREADS + tid;
-            const int row = idx / C::SLOTS, slot = idx % C::SLOTS;
-            const int off = row * C::ROWB + ((slot ^ (row & (C::SLOTS - 1))) << 4);
-            *reinterpret_cast<uint4*>(Kl + off) = kst[ps];
-            uint4 v = vst[ps];
-            if (ragged) v = mask_keys<T>(v, kv0 + slot * (16 / (int)sizeof(T)), Nkv);
-            *reinterpret_cast<uint4*>(Vl + off) = v;
-        }
-    };
-
-    issue_loads(0);
-    write_lds(0);
-    __syncthreads();
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    stage_tiles<T>(lds, Kbh, Vbh, v_row_bytes, 0, wave_u, lane);
 
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) issue_loads(t + 1);
+        unsigned char* Kl = lds + (t & 1) * STAGE_BYTES;
+        unsigned char* Vl = Kl + TILE_BYTES;
         const int kv0 = t * KT;
-
-        // ---- S^T = K . Q^T : 4 key tiles x 2 query tiles
-        f32x4_t s[4][2];
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf) {
-            s[kf][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            s[kf][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            const int krow = key_of_row<T>(kf, l15);
-#pragma unroll
-            for (int c = 0; c < C::NCH; ++c) {
-                const uint4 kfrag = lds_chunk<T>(Kl, krow, c * 4 + g);
-                Mma<T>::run(s[kf][0], kfrag, qreg[0][c]);
-                Mma<T>::run(s[kf][1], kfrag, qreg[1][c]);
-            }
-        }
-        // mask keys beyond Nkv (only the last tile can be ragged)
+        // this wave's DMA of tile t has landed; after the barrier everybody's has, and every wave is done with
+        // the other stage (tile t-1), which the DMA of tile t+1 may now overwrite while tile t is multiplied
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntiles) stage_tiles<T>(lds + ((t + 1) & 1) * STAGE_BYTES, Kbh, Vbh, v_row_bytes, t + 1, wave_u, lane);
         if (kv0 + KT > Nkv) {
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kv0 + key_of_row<T>(kf, 4 * g + r);
-                    if (key >= Nkv) { s[kf][0][r] = -INFINITY; s[kf][1][r] = -INFINITY; }
-                }
+            zero_ragged_v<T>(Vl, kv0, Nkv, tid);
+            __syncthreads();
         }
-        // ---- online softmax per query column
+
+        // The 64-key tile is consumed as two 32-key halves (S^T tiles 2*pc, 2*pc+1): half the S registers,
+        // and the softmax VALU of one half overlaps the MFMAs of the other across the co-resident waves.
 #pragma unroll
-        for (int qf = 0; qf < 2; ++qf) {
-            float tmax = s[0][qf][0];
+        for (int pc = 0; pc < 2; ++pc) {
+            // ---- S^T = K . Q^T : 2 key tiles x QF query tiles
+            f32x4_t s[2][QF];
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kf][qf][r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float mnew = fmaxf(mrun[qf], tmax);      // finite: every tile has >= 1 valid key
-            const float alpha = EXP2 ? __builtin_amdgcn_exp2f(mrun[qf] - mnew) : expf(mrun[qf] - mnew);
-            mrun[qf] = mnew;
-            float psum = 0.f;
+                for (int qf = 0; qf < QF; ++qf) s[kk][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                const int krow = key_of_row<T>(2 * pc + kk, l15);
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
+                for (int c = 0; c < C::NCH; ++c) {
+                    const uint4 kfrag = lds_chunk<T>(Kl, krow, c * 4 + g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = EXP2 ? __builtin_amdgcn_exp2f(s[kf][qf][r] - mnew) : expf(s[kf][qf][r] - mnew);
-                    s[kf][qf][r] = pv;
-                    psum += pv;
+                    for (int qf = 0; qf < QF; ++qf) Mma<T>::run(s[kk][qf], kfrag, qreg[qf][c]);
                 }
-            lrun[qf] = lrun[qf] * alpha + psum;
-#pragma unroll
-            for (int df = 0; df < 4; ++df) {
-                o[df][qf][0] *= alpha; o[df][qf][1] *= alpha; o[df][qf][2] *= alpha; o[df][qf][3] *= alpha;
             }
-        }
-        // ---- O^T += V^T . P^T
-        if constexpr (sizeof(T) == 2) {
+            // mask keys beyond Nkv (only the last tile can be ragged)
+            if (kv0 + KT > Nkv) {
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                const uint4 p0 = pack_p<bf16_t>(s[2 * pc][0], s[2 * pc + 1][0]);
-                const uint4 p1 = pack_p<bf16_t>(s[2 * pc][1], s[2 * pc + 1][1]);
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kv0 + key_of_row<T>(2 * pc + kk, 4 * g + r);
+                        if (key >= Nkv) {
+#pragma unroll
+                            for (int qf = 0; qf < QF; ++qf) s[kk][qf][r] = -INFINITY;
+                        }
+                    }
+            }
+            // ---- online softmax per query column
+            float tmax[QF];
+            bool grow = false;
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) {
+                float m = fmaxf(fmaxf(fmaxf(s[0][qf][0], s[0][qf][1]), fmaxf(s[0][qf][2], s[0][qf][3])),
+                                fmaxf(fmaxf(s[1][qf][0], s[1][qf][1]), fmaxf(s[1][qf][2], s[1][qf][3])));
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                tmax[qf] = m;
+                grow |= (m - mrun[qf] > kDefer);             // first half-tile: mrun = -inf -> true
+            }
+            if (__any(grow)) {                               // wave-uniform: rescale everything at the old max exactly once
+#pragma unroll
+                for (int qf = 0; qf < QF; ++qf) {
+                    // a half-tile of a ragged last tile may be fully masked (tmax = -inf): keep the max finite
+                    const float mnew = fmaxf(fmaxf(mrun[qf], tmax[qf]), -1e30f);
+                    const float alpha = EXP2 ? __builtin_amdgcn_exp2f(mrun[qf] - mnew) : expf(mrun[qf] - mnew);
+                    mrun[qf] = mnew;
+                    lrun[qf] *= alpha;
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) {
+                        o[df][qf][0] *= alpha; o[df][qf][1] *= alpha; o[df][qf][2] *= alpha; o[df][qf][3] *= alpha;
+                    }
+                }
+            }
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) {
+                const float m = mrun[qf];
+                float psum = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = EXP2 ? __builtin_amdgcn_exp2f(s[kk][qf][r] - m) : expf(s[kk][qf][r] - m);
+                        s[kk][qf][r] = pv;
+                        psum += pv;
+                    }
+                lrun[qf] += psum;
+            }
+            // ---- O^T += V^T . P^T
+            if constexpr (sizeof(T) == 2) {
+                uint4 pfrag[QF];
+#pragma unroll
+                for (int qf = 0; qf < QF; ++qf) pfrag[qf] = pack_p<bf16_t>(s[0][qf], s[1][qf]);
 #pragma unroll
                 for (int df = 0; df < 4; ++df) {
                     const uint4 vfrag = lds_chunk<T>(Vl, df * 16 + l15, pc * 4 + g);
-                    Mma<T>::run(o[df][0], vfrag, p0);
-                    Mma<T>::run(o[df][1], vfrag, p1);
+#pragma unroll
+                    for (int qf = 0; qf < QF; ++qf) Mma<T>::run(o[df][qf], vfrag, pfrag[qf]);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    uint4 pfrag[QF];
+#pragma unroll
+                    for (int qf = 0; qf < QF; ++qf)
+                        pfrag[qf] = make_uint4(__float_as_uint(s[kk][qf][0]), __float_as_uint(s[kk][qf][1]),
+                                               __float_as_uint(s[kk][qf][2]), __float_as_uint(s[kk][qf][3]));
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) {
+                        const uint4 vfrag = lds_chunk<T>(Vl, df * 16 + l15, (2 * pc + kk) * 4 + g);
+#pragma unroll
+                        for (int qf = 0; qf < QF; ++qf) Mma<T>::run(o[df][qf], vfrag, pfrag[qf]);
+                    }
                 }
             }
-        } else {
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf) {
-                const uint4 p0 = make_uint4(__float_as_uint(s[kf][0][0]), __float_as_uint(s[kf][0][1]),
-                                            __float_as_uint(s[kf][0][2]), __float_as_uint(s[kf][0][3]));
-                const uint4 p1 = make_uint4(__float_as_uint(s[kf][1][0]), __float_as_uint(s[kf][1][1]),
-                                            __float_as_uint(s[kf][1][2]), __float_as_uint(s[kf][1][3]));
-#pragma unroll
-                for (int df = 0; df < 4; ++df) {
-                    const uint4 vfrag = lds_chunk<T>(Vl, df * 16 + l15, kf * 4 + g);
-                    Mma<T>::run(o[df][0], vfrag, p0);
-                    Mma<T>::run(o[df][1], vfrag, p1);
-                }
-            }
-        }
-        __syncthreads();                      // everyone is done reading this tile
-        if (t + 1 < ntiles) {
-            write_lds(t + 1);
-            __syncthreads();
         }
     }
 
     // ---- finalize: O = O^T / l, head-major inside the output row
-    float inv[2];
+    float inv[QF];
 #pragma unroll
-    for (int qf = 0; qf < 2; ++qf) {      // cross-lane steps first, outside any divergent region
+    for (int qf = 0; qf < QF; ++qf) {      // cross-lane steps first, outside any divergent region
         float l = lrun[qf];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         inv[qf] = 1.0f / l;
     }
 #pragma unroll
-    for (int qf = 0; qf < 2; ++qf) {
+    for (int qf = 0; qf < QF; ++qf) {
         const int q = q0 + qf * 16 + l15;
         if (q < Nq) {
             T* orow = out + ((size_t)b * Nq + q) * ldo + h * DH;
@@ -273,21 +304,23 @@ extern "C" int pmhip_attention(int dtype, const void* Q, const void* K, const vo
     PM_REQUIRE(Nkv_pad % KT == 0 && Nkv_pad >= Nkv, "attention: Nkv_pad=%d must be a multiple of 64 >= Nkv=%d", Nkv_pad, Nkv);
     PM_REQUIRE(ldo % 4 == 0, "attention: ldo must be a multiple of 4");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(ceil_div(Nq, QB), B * heads), block(THREADS);
+    dim3 block(THREADS);
     PmTimer tm(FAM_ATTENTION, s);
     if (dtype == PMHIP_F32) {
+        dim3 grid(ceil_div(Nq, 4 * 2 * 16), B * heads);
         if (use_exp2)
-            hipLaunchKernelGGL((attention_kernel<float, true>), grid, block, 0, s, (const float*)Q, (const float*)K,
+            hipLaunchKernelGGL((attention_kernel<float, true, 2>), grid, block, 0, s, (const float*)Q, (const float*)K,
                                (const float*)Vt, (float*)out, ldo, heads, Nq, Nkv, Nkv_pad);
         else
-            hipLaunchKernelGGL((attention_kernel<float, false>), grid, block, 0, s, (const float*)Q, (const float*)K,
+            hipLaunchKernelGGL((attention_kernel<float, false, 2>), grid, block, 0, s, (const float*)Q, (const float*)K,
                                (const float*)Vt, (float*)out, ldo, heads, Nq, Nkv, Nkv_pad);
     } else {
+        dim3 grid(ceil_div(Nq, 4 * 4 * 16), B * heads);
         if (use_exp2)
-            hipLaunchKernelGGL((attention_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K,
+            hipLaunchKernelGGL((attention_kernel<bf16_t, true, 4>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K,
                                (const bf16_t*)Vt, (bf16_t*)out, ldo, heads, Nq, Nkv, Nkv_pad);
         else
-            hipLaunchKernelGGL((attention_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K,
+            hipLaunchKernelGGL((attention_kernel<bf16_t, false, 4>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K,
                                (const bf16_t*)Vt, (bf16_t*)out, ldo, heads, Nq, Nkv, Nkv_pad);
     }
     PM_HIP(hipGetLastError());

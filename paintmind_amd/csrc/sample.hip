@@ -51,6 +51,9 @@ __device__ __forceinline__ float gumbel_from_uniform(float u) {
     return -logf(fmaxf(inner, 1e-20f));
 }
 
+// Row layout in registers: lane l holds float4 group g (g = 0..NV4-1) = columns (g*64 + l)*4 .. +3,
+// so a lane's columns increase with g and groups are disjoint contiguous column ranges: ordering
+// candidates by (value desc, first column of their group asc) equals (value desc, column asc).
 template <int NV4>
 __global__ __launch_bounds__(THREADS) void sample_rows_kernel(
     const float* __restrict__ logits, int ldl, const int64_t* __restrict__ ids_in, int64_t mask_id, int topk,
@@ -61,44 +64,54 @@ __global__ __launch_bounds__(THREADS) void sample_rows_kernel(
     if (row >= M) return;                                  // whole wave exits together
     const float* lrow = logits + (size_t)row * ldl;
 
-    float x[NV4 * 4];
+    float4 x[NV4];
 #pragma unroll
-    for (int i = 0; i < NV4; ++i) {
-        const int col = (i * 64 + lane) * 4;
-        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        if (col < V) v = *reinterpret_cast<const float4*>(lrow + col);
-        x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+    for (int g = 0; g < NV4; ++g) {
+        const int col = (g * 64 + lane) * 4;
+        x[g] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (col < V) x[g] = *reinterpret_cast<const float4*>(lrow + col);
     }
-    // ---- softmax normaliser
+    // ---- softmax normaliser of the UNfiltered row (generate.py:170)
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < NV4 * 4; ++i) mx = fmaxf(mx, x[i]);
+    for (int g = 0; g < NV4; ++g) mx = fmaxf(mx, fmaxf(fmaxf(x[g].x, x[g].y), fmaxf(x[g].z, x[g].w)));
     mx = wave_max(mx);
     float se = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV4 * 4; ++i) se += expf(x[i] - mx);
+    for (int g = 0; g < NV4; ++g)
+        se += (__expf(x[g].x - mx) + __expf(x[g].y - mx)) + (__expf(x[g].z - mx) + __expf(x[g].w - mx));
     se = wave_sum(se);
 
-    // ---- top-k by k rounds of "best element strictly after the previous winner"
-    float pv = INFINITY;
-    int pi = -1;
+    // ---- top-k: k rounds of {per-lane best group, wave arg-max, winner removes its element}
     Cand mine{-INFINITY, 0x7fffffff};                      // candidate r is kept by lane r
 #pragma unroll 1
     for (int r = 0; r < topk; ++r) {
-        Cand c{-INFINITY, 0x7fffffff};
+        float bv = -INFINITY;
+        int bg = 0;
 #pragma unroll
-        for (int i = 0; i < NV4; ++i) {
+        for (int g = 0; g < NV4; ++g) {
+            const float m4 = fmaxf(fmaxf(x[g].x, x[g].y), fmaxf(x[g].z, x[g].w));
+            if (m4 > bv) { bv = m4; bg = g; }              // strict: the first (lowest-column) group wins ties
+        }
+        Cand c{bv, (bg * 64 + lane) * 4};
+        c = wave_best(c);
+        // the owner lane finds the element inside the winning group and retires it
+        const int wg = __builtin_amdgcn_readfirstlane(c.i >> 8);          // c.i = (g*64+lane)*4 -> g = c.i / 256
+        const int wl = (c.i >> 2) & 63;
+        int col = c.i;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = x[4 * i + e];
-                const int idx = (i * 64 + lane) * 4 + e;
-                const bool eligible = (idx < V) && before(pv, pi, v, idx);
-                if (eligible && before(v, idx, c.v, c.i)) { c.v = v; c.i = idx; }
+        for (int g = 0; g < NV4; ++g) {
+            if (g == wg) {                                                // wave-uniform branch
+                if (lane == wl) {
+                    if (x[g].x == c.v) { x[g].x = -INFINITY; col = c.i; }
+                    else if (x[g].y == c.v) { x[g].y = -INFINITY; col = c.i + 1; }
+                    else if (x[g].z == c.v) { x[g].z = -INFINITY; col = c.i + 2; }
+                    else { x[g].w = -INFINITY; col = c.i + 3; }
+                }
             }
         }
-        c = wave_best(c);
-        pv = c.v; pi = c.i;
-        if (lane == r) mine = c;
+        col = __shfl(col, wl, 64);
+        if (lane == r) { mine.v = c.v; mine.i = col; }
     }
     // ---- gumbel arg-max among the candidates (lane r evaluates candidate r)
     Cand pert{-INFINITY, 0x7fffffff};
@@ -115,7 +128,6 @@ __global__ __launch_bounds__(THREADS) void sample_rows_kernel(
         pert.v = mine.v / fmaxf(temperature, 1e-10f) + gumbel_from_uniform(u);
         pert.i = mine.i;
     }
-    // remember each candidate's raw logit: the winner's lane broadcasts it afterwards
     const Cand win = wave_best(pert);
     const unsigned long long owner = __ballot(lane < topk && mine.i == win.i);
     const int src = owner ? __ffsll((long long)owner) - 1 : 0;
