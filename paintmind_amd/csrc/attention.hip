@@ -29,13 +29,11 @@ template <> struct AttnCfg<bf16_t> {
     static constexpr int ROWB = 128;     // bytes per K row (64 d) == bytes per V^T row segment (64 keys)
     static constexpr int SLOTS = 8;
     static constexpr int NCH = 2;        // 16-B chunks x4 lane groups per 64-wide contraction
-    static constexpr int PASSES = 2;     // 256 threads x 16 B per pass to stage one 8 KiB tile
 };
 template <> struct AttnCfg<float> {
     static constexpr int ROWB = 256;
     static constexpr int SLOTS = 16;
     static constexpr int NCH = 4;
-    static constexpr int PASSES = 4;
 };
 
 // tile row (key within the 64-key tile) that S^T tile kf presents as its row i (i = 0..15)

@@ -87,6 +87,24 @@ __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, flo
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
 }
 
+// store 16 consecutive elements (p is 16-byte aligned)
+__device__ __forceinline__ void store16(float* p, const float (&v)[16]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(p + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+__device__ __forceinline__ void store16(bf16_t* p, const float (&v)[16]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    *reinterpret_cast<uint4*>(p + 8) = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+}
+
+// one 16-byte store: 4 floats or 8 bf16
+__device__ __forceinline__ void store_row(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store_row(bf16_t* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+
 // One 16-byte operand chunk per lane feeds the matrix core:
 //   bf16: 8 k-values  -> one  v_mfma_f32_16x16x32_bf16
 //   f32 : 4 k-values  -> four v_mfma_f32_16x16x4_f32 (exact f32, == an fmaf chain)

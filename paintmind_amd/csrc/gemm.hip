@@ -9,7 +9,8 @@
 // step t is multiplied.
 //
 // The MFMA is issued with W as the row operand and A as the column operand, so each lane ends up
-// with 4 CONSECUTIVE n for one m: bias/residual are float4 loads and stores are 8/16 B wide.
+// with 4 consecutive n for one m; the epilogue transposes 16 rows at a time through the idle LDS stage
+// so that bias / residual loads and all stores are 128-256 contiguous bytes per row.
 //
 // Replaces torch.nn.Linear / aten::addmm at: modules/attention.py:46-49,59; modules/mlp.py:27-31;
 // stage1/vqmodel.py:23,28; stage1/layers.py:107 (patch-embed conv as GEMM),149;
@@ -23,6 +24,8 @@ constexpr int ROWB = 128;                          // bytes of k per tile row pe
 constexpr int TILE_BYTES = 128 * ROWB;             // one operand tile, 16 KiB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;        // A tile + W tile
 constexpr int THREADS = 256;
+
+constexpr int ESTRIDE = 68;                       // floats per row of the per-wave epilogue buffer (64 + pad)
 
 enum { EPI_STD = 0, EPI_SWIGLU = 1, EPI_HEADS = 2 };
 
@@ -84,11 +87,18 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
 
-    const int tiles_n = (p.N + BN - 1) / BN;
+    // Tile walk: n-tiles are visited in chunks of <= 8 (<= 1 MiB of W in bf16) with m-tiles varying inside a
+    // chunk, so that an XCD's resident blocks share one W chunk + a few A row panels inside its 4 MiB L2.
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int nblocks = gridDim.x;
     const int vb = xcd_remap(blockIdx.x, nblocks);
-    const int m0 = (vb / tiles_n) * BM;
-    const int n0 = (vb % tiles_n) * BN;
+    const int nchunks = (tiles_n + 7) / 8;
+    const int cw = (tiles_n + nchunks - 1) / nchunks;              // n-tiles per chunk (last chunk may be narrower)
+    const int chunk = vb / (tiles_m * cw);
+    const int cw_here = min(cw, tiles_n - chunk * cw);
+    const int rem = vb - chunk * tiles_m * cw;
+    const int m0 = (rem / cw_here) * BM;
+    const int n0 = (chunk * cw + rem % cw_here) * BN;
 
     const T* A = reinterpret_cast<const T*>(p.A);
     const T* W = reinterpret_cast<const T*>(p.W);
@@ -100,6 +110,29 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // epilogue geometry (see below): one store instruction = RPI rows x 64 columns of this wave's tile
+    constexpr int CPL = 16 / (int)sizeof(OutT);                    // columns per lane per store (16 B)
+    constexpr int LPR = 64 / CPL, RPI = 64 / LPR, ITERS = 16 / RPI;
+    const int nw = n0 + wn * 64;                                   // first column of this wave
+    const int ccol = (lane % LPR) * CPL, ncol = nw + ccol;
+
+    // The residual tile is fetched BEFORE the K loop into registers (its HBM latency would otherwise sit,
+    // exposed, between the last MFMA and the stores).  Only the f32-output epilogue carries a residual.
+    float4 rpre[EPI == EPI_STD && sizeof(OutT) == 4 ? 16 : 1];
+    if constexpr (EPI == EPI_STD && sizeof(OutT) == 4) {
+        if (p.residual) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    int mm = m0 + wm * 64 + mi * 16 + it * RPI + lane / LPR;
+                    mm = mm < p.M ? mm : p.M - 1;
+                    const int nc = ncol < p.N ? ncol : 0;
+                    rpre[mi * ITERS + it] = *reinterpret_cast<const float4*>(p.residual + (size_t)(mm % p.res_rows) * p.ldr + nc);
+                }
+        }
+    }
 
     stage_tile<T>(A, p.lda, m0, p.M, 0, lds, wave, lane);
     stage_tile<T>(W, p.ldw, n0, p.N, 0, lds + TILE_BYTES, wave, lane);
@@ -133,86 +166,125 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
     }
 
     // ------------------------------------------------------------------ epilogue
-    // lane holds, for tile (mi, ni): m = .. + l15 ; n = .. + 4*g + r (r = 0..3)
+    // The MFMA result layout gives a lane 4 consecutive n of ONE row, i.e. 16 rows x 64 B per store
+    // instruction.  Each wave therefore transposes its tile, 16 rows at a time, through the LDS stage that
+    // is idle after the K loop (stage nk&1: its last reads finished before the final barrier), so that
+    // 4 lanes cover one row's 64 columns: bias / residual loads and the stores are 256 B (f32) or 128 B
+    // (bf16) contiguous per row.
+    float* ebuf = reinterpret_cast<float*>(lds + (nk & 1) * STAGE_BYTES) + wave * (16 * ESTRIDE);
+    const int erow = lane >> 2;
+    float bias_v[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) bias_v[j] = 0.f;
     if constexpr (EPI == EPI_STD) {
-        OutT* out = reinterpret_cast<OutT*>(p.out);
+        if (p.bias && ncol < p.N) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm * 64 + mi * 16 + l15;
-            if (m >= p.M) continue;
-            const float* rrow = p.residual ? p.residual + (size_t)(m % p.res_rows) * p.ldr : nullptr;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int nb = n0 + wn * 64 + ni * 16 + g * 4;
-                if (nb >= p.N) continue;
-                float v0 = acc[mi][ni][0], v1 = acc[mi][ni][1], v2 = acc[mi][ni][2], v3 = acc[mi][ni][3];
-                if (p.bias) {
-                    const float4 b = *reinterpret_cast<const float4*>(p.bias + nb);
-                    v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
-                }
-                if (rrow) {
-                    const float4 rr = *reinterpret_cast<const float4*>(rrow + nb);
-                    v0 += rr.x; v1 += rr.y; v2 += rr.z; v3 += rr.w;
-                }
-                store4(out + (size_t)m * p.ldo + nb, v0, v1, v2, v3);
+            for (int j = 0; j < CPL; j += 4) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + ncol + j);
+                bias_v[j] = bb.x; bias_v[j + 1] = bb.y; bias_v[j + 2] = bb.z; bias_v[j + 3] = bb.w;
             }
         }
-    } else if constexpr (EPI == EPI_SWIGLU) {
-        // packed rows: [16 rows of x1 | the same 16 rows of x2] repeated, so tiles (2p, 2p+1) of a
-        // wave hold x1 and x2 of the SAME hidden columns in the SAME lanes
-        OutT* out = reinterpret_cast<OutT*>(p.out);
+    }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm * 64 + mi * 16 + l15;
-            if (m >= p.M) continue;
+    for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int n1 = n0 + wn * 64 + (2 * pr) * 16 + g * 4;     // packed row of x1
-                const int n2 = n1 + 16;                                   // packed row of x2
-                if (n1 >= p.N) continue;
-                const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n1);
-                const float4 b2 = *reinterpret_cast<const float4*>(p.bias + n2);
-                const f32x4_t a1 = acc[mi][2 * pr], a2 = acc[mi][2 * pr + 1];
-                const int j = ((n0 + wn * 64) >> 1) + pr * 16 + g * 4;    // hidden column
-                store4(out + (size_t)m * p.ldo + j,
-                       silu_mul(a1[0] + b1.x, a2[0] + b2.x, p.fast_math),
-                       silu_mul(a1[1] + b1.y, a2[1] + b2.y, p.fast_math),
-                       silu_mul(a1[2] + b1.z, a2[2] + b2.z, p.fast_math),
-                       silu_mul(a1[3] + b1.w, a2[3] + b2.w, p.fast_math));
+        for (int ni = 0; ni < 4; ++ni)
+            *reinterpret_cast<f32x4_t*>(ebuf + l15 * ESTRIDE + ni * 16 + g * 4) = acc[mi][ni];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int mbase = m0 + wm * 64 + mi * 16;
+        const int m = mbase + erow;
+        if constexpr (EPI == EPI_STD) {
+            // one store instruction = RPI rows x 64 columns, LPR adjacent lanes per row (full 128-B lines)
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int r = it * RPI + lane / LPR;
+                const int mm = mbase + r;
+                if (mm < p.M && ncol < p.N) {
+                    float v[CPL];
+#pragma unroll
+                    for (int j = 0; j < CPL; j += 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(ebuf + r * ESTRIDE + ccol + j);
+                        v[j] = t.x + bias_v[j]; v[j + 1] = t.y + bias_v[j + 1]; v[j + 2] = t.z + bias_v[j + 2]; v[j + 3] = t.w + bias_v[j + 3];
+                    }
+                    if constexpr (sizeof(OutT) == 4) {
+                        if (p.residual) {
+                            const float4 rr = rpre[mi * ITERS + it];
+                            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                        }
+                    }
+                    store_row(reinterpret_cast<OutT*>(p.out) + (size_t)mm * p.ldo + ncol, v);
+                }
             }
-        }
-    } else {  // EPI_HEADS: a wave's 64 n-columns are exactly one head of one part
-        const int nw = n0 + wn * 64;
-        if (nw < p.N) {
-            const int part = nw / p.inner;
-            const int h = (nw % p.inner) >> 6;
-            const int kind = p.kinds[part];
-            OutT* dst = reinterpret_cast<OutT*>(p.outs[part]);
+        } else if constexpr (EPI == EPI_SWIGLU) {
+            // wave columns: [x1 0-15 | x2 0-15 | x1 16-31 | x2 16-31] of 32 hidden columns; lane (erow, q) gates
+            // hidden columns q*8 .. q*8+7
+            if (m < p.M && nw < p.N) {
+                const int q = lane & 3;
+                const int c1 = (q >> 1) * 32 + (q & 1) * 8;          // x1 column inside the wave tile
+                const float* e1 = ebuf + erow * ESTRIDE + c1;
+                const float4 a0 = *reinterpret_cast<const float4*>(e1), a1 = *reinterpret_cast<const float4*>(e1 + 4);
+                const float4 g0 = *reinterpret_cast<const float4*>(e1 + 16), g1 = *reinterpret_cast<const float4*>(e1 + 20);
+                const float* b1 = p.bias + nw + c1;
+                const float4 ba0 = *reinterpret_cast<const float4*>(b1), ba1 = *reinterpret_cast<const float4*>(b1 + 4);
+                const float4 bg0 = *reinterpret_cast<const float4*>(b1 + 16), bg1 = *reinterpret_cast<const float4*>(b1 + 20);
+                float h[8];
+                h[0] = silu_mul(a0.x + ba0.x, g0.x + bg0.x, p.fast_math); h[1] = silu_mul(a0.y + ba0.y, g0.y + bg0.y, p.fast_math);
+                h[2] = silu_mul(a0.z + ba0.z, g0.z + bg0.z, p.fast_math); h[3] = silu_mul(a0.w + ba0.w, g0.w + bg0.w, p.fast_math);
+                h[4] = silu_mul(a1.x + ba1.x, g1.x + bg1.x, p.fast_math); h[5] = silu_mul(a1.y + ba1.y, g1.y + bg1.y, p.fast_math);
+                h[6] = silu_mul(a1.z + ba1.z, g1.z + bg1.z, p.fast_math); h[7] = silu_mul(a1.w + ba1.w, g1.w + bg1.w, p.fast_math);
+                OutT* out = reinterpret_cast<OutT*>(p.out) + (size_t)m * p.ldo + (nw >> 1) + q * 8;
+                store4(out, h[0], h[1], h[2], h[3]);
+                store4(out + 4, h[4], h[5], h[6], h[7]);
+            }
+        } else {  // EPI_HEADS: the wave's 64 columns are exactly one head of one part
+            if (nw < p.N) {
+                const int part = nw / p.inner;
+                const int h = (nw % p.inner) >> 6;
+                const int kind = p.kinds[part];
+                OutT* dst = reinterpret_cast<OutT*>(p.outs[part]);
+                if (kind != PMHIP_PART_V) {
+                    const int tstride = kind == PMHIP_PART_Q ? p.tokens : p.tokens_pad;
+                    const float sc = kind == PMHIP_PART_Q ? p.q_scale : 1.0f;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int m = m0 + wm * 64 + mi * 16 + l15;
-                if (m >= p.M) continue;
-                const int b = m / p.tokens, t = m % p.tokens;
-                const size_t bh = (size_t)b * p.heads + h;
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int r = it * RPI + lane / LPR;
+                        const int mm = mbase + r;
+                        if (mm < p.M) {
+                            const int b = mm / p.tokens, t = mm % p.tokens;
+                            float v[CPL];
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int d = ni * 16 + g * 4;
-                    const f32x4_t a = acc[mi][ni];
-                    if (kind == PMHIP_PART_Q) {
-                        store4(dst + (bh * p.tokens + t) * 64 + d, a[0] * p.q_scale, a[1] * p.q_scale,
-                               a[2] * p.q_scale, a[3] * p.q_scale);
-                    } else if (kind == PMHIP_PART_K) {
-                        store4(dst + (bh * p.tokens_pad + t) * 64 + d, a[0], a[1], a[2], a[3]);
+                            for (int j = 0; j < CPL; j += 4) {
+                                const float4 t4 = *reinterpret_cast<const float4*>(ebuf + r * ESTRIDE + ccol + j);
+                                v[j] = t4.x * sc; v[j + 1] = t4.y * sc; v[j + 2] = t4.z * sc; v[j + 3] = t4.w * sc;
+                            }
+                            store_row(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + ccol, v);
+                        }
+                    }
+                } else {
+                    // V^T[b,h,d,t]: lane = d, its 16 values are 16 consecutive tokens
+                    const int d = lane;
+                    const int b0 = mbase / p.tokens, t0 = mbase % p.tokens;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = ebuf[r * ESTRIDE + d];
+                    if (mbase + 15 < p.M && t0 + 15 < p.tokens && (t0 & 7) == 0) {
+                        store16(dst + (((size_t)b0 * p.heads + h) * 64 + d) * p.tokens_pad + t0, v);
                     } else {
-                        OutT* vt = dst + (bh * 64 + d) * p.tokens_pad + t;
-                        vt[0] = from_f32<OutT>(a[0]);
-                        vt[(size_t)p.tokens_pad] = from_f32<OutT>(a[1]);
-                        vt[(size_t)2 * p.tokens_pad] = from_f32<OutT>(a[2]);
-                        vt[(size_t)3 * p.tokens_pad] = from_f32<OutT>(a[3]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int mm = mbase + r;
+                            if (mm < p.M) {
+                                const int b = mm / p.tokens, t = mm % p.tokens;
+                                dst[(((size_t)b * p.heads + h) * 64 + d) * p.tokens_pad + t] = from_f32<OutT>(v[r]);
+                            }
+                        }
                     }
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next 16 rows overwrite ebuf
     }
 }
 
@@ -247,7 +319,9 @@ extern "C" int pmhip_gemm(int dtype, const void* A, int lda, const void* W, int 
     PM_REQUIRE(out, "gemm: null out");
     PM_REQUIRE(N % 4 == 0 && ldo % 4 == 0, "gemm: N=%d and ldo=%d must be multiples of 4", N, ldo);
     PM_REQUIRE(!residual || ldr % 4 == 0, "gemm: ldr must be a multiple of 4");
+    PM_REQUIRE(!residual || out_dtype == PMHIP_F32, "gemm: a residual needs an f32 output (the residual stream is f32)");
     PM_REQUIRE(out_dtype == PMHIP_F32 || out_dtype == dtype, "gemm: out dtype must be f32 or the compute dtype");
+    PM_REQUIRE(out_dtype == PMHIP_F32 || ldo % 8 == 0, "gemm: bf16 output needs ldo to be a multiple of 8");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PMHIP_F32) return launch<float, EPI_STD, float>(p, s);
     if (out_dtype == PMHIP_F32) return launch<bf16_t, EPI_STD, float>(p, s);
@@ -262,7 +336,7 @@ extern "C" int pmhip_gemm_swiglu(int dtype, const void* A, int lda, const void* 
     p.fast_math = (dtype == PMHIP_BF16);
     PM_TRY(check_common(p, dtype));
     PM_REQUIRE(Hp % 64 == 0, "gemm_swiglu: padded hidden width %d must be a multiple of 64", Hp);
-    PM_REQUIRE(b12p && out && ldo % 4 == 0, "gemm_swiglu: bias/out required, ldo multiple of 4");
+    PM_REQUIRE(b12p && out && ldo % 8 == 0, "gemm_swiglu: bias/out required, ldo multiple of 8");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PMHIP_F32) return launch<float, EPI_SWIGLU, float>(p, s);
     return launch<bf16_t, EPI_SWIGLU, bf16_t>(p, s);
