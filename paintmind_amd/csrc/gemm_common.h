@@ -1,0 +1,218 @@
+// Shared pieces of the NT GEMM family (gemm.hip: 128x128 tile; gemm256.hip: 256x256 phase-staggered tile):
+// parameter block, tile-walk helpers and the wave-level epilogue.
+#pragma once
+#include "common.h"
+
+namespace pmgemm {
+
+constexpr int ROWB = 128;                          // bytes of k per tile row per step (64 bf16 / 32 f32)
+constexpr int ESTRIDE = 68;                        // floats per row of the per-wave epilogue buffer (64 + pad)
+constexpr int EPI_WAVE_BYTES = 8192;               // idle LDS each wave needs for its epilogue
+
+enum { EPI_STD = 0, EPI_SWIGLU = 1, EPI_HEADS = 2 };
+
+struct GemmParams {
+    const void* A; const void* W;
+    const float* bias; const float* residual;
+    void* out;
+    int lda, ldw, ldr, res_rows, ldo;
+    int M, N, K;
+    // EPI_HEADS
+    int heads, tokens, tokens_pad, inner;
+    int kinds[3];
+    void* outs[3];
+    float q_scale;
+    int fast_math;                                 // SwiGLU: 1 = fast exp (bf16 mode)
+};
+
+// XCD-aware, bijective block remap: consecutive virtual ids stay on one XCD's L2 (block b runs on XCD b % 8).
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+// Tile walk: n-tiles are visited in chunks of at most `max_chunk` tiles with m-tiles varying inside a chunk, so
+// that an XCD's resident blocks share one W chunk (<= 1 MiB in bf16) + a few A row panels inside its 4 MiB L2.
+__device__ __forceinline__ void tile_of_block(int vb, int tiles_m, int tiles_n, int max_chunk, int& tm, int& tn) {
+    const int nchunks = (tiles_n + max_chunk - 1) / max_chunk;
+    const int cw = (tiles_n + nchunks - 1) / nchunks;              // n-tiles per chunk (the last may be narrower)
+    const int chunk = vb / (tiles_m * cw);
+    const int cw_here = min(cw, tiles_n - chunk * cw);
+    const int rem = vb - chunk * tiles_m * cw;
+    tm = rem / cw_here;
+    tn = chunk * cw + rem % cw_here;
+}
+
+__device__ __forceinline__ uint4 read_frag(const unsigned char* lds_tile, int row, int slot) {
+    return *reinterpret_cast<const uint4*>(lds_tile + row * ROWB + ((slot ^ (row & 7)) << 4));
+}
+
+__device__ __forceinline__ float silu_mul(float x1, float x2, int fast) {
+    const float e = fast ? __expf(-x1) : expf(-x1);
+    return (x1 / (1.0f + e)) * x2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-level epilogue for a (MI*16) x 64 accumulator tile held as acc[MI][4] (MFMA issued with W as the row
+// operand: a lane owns row l15 of a 16-row group and 4 consecutive columns per 16x16 tile).  The tile is
+// transposed 16 rows at a time through `eraw` (>= EPI_WAVE_BYTES of LDS nobody else touches) so that every
+// global access covers 128-256 contiguous bytes per row.  `rpre` (used when NPRE > 1) holds the residual tile
+// prefetched in the store layout: element [mi*ITERS + it].
+// ------------------------------------------------------------------------------------------------
+template <int EPI, typename OutT, int MI, int NPRE>
+__device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][4], unsigned char* eraw, int mwave,
+                                              int nw, int lane, const float4 (&rpre)[NPRE]) {
+    constexpr int CPL = 16 / (int)sizeof(OutT);                    // columns per lane per store (16 B)
+    constexpr int LPR = 64 / CPL, RPI = 64 / LPR, ITERS = 16 / RPI;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int ccol = (lane % LPR) * CPL, ncol = nw + ccol;
+    float* ebuf = reinterpret_cast<float*>(eraw);
+    if (nw >= p.N) return;
+
+    if constexpr (EPI == EPI_HEADS) {
+        // V part: 64-token x 64-d blocks are transposed through LDS as OutT so that V^T[b,h,d,:] rows are written
+        // 128 B (bf16) at a time; Q and K take the generic 16-row path below.
+        if (p.kinds[nw / p.inner] == PMHIP_PART_V) {
+            const int h = (nw % p.inner) >> 6;
+            OutT* dst = reinterpret_cast<OutT*>(p.outs[nw / p.inner]);
+#pragma unroll
+            for (int blk = 0; blk < MI / 4; ++blk) {
+                const int mblk = mwave + blk * 64;
+                const int b0 = mblk / p.tokens, t0 = mblk % p.tokens;
+                const bool whole = (mblk + 63 < p.M) && (t0 + 63 < p.tokens) && (t0 % 8 == 0);
+                if (whole && sizeof(OutT) == 2) {
+                    OutT* vbuf = reinterpret_cast<OutT*>(eraw);                  // [64 d][64 tokens]
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                vbuf[(ni * 16 + g * 4 + r) * 64 + mi * 16 + l15] = from_f32<OutT>(acc[blk * 4 + mi][ni][r]);
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    OutT* vrow = dst + (((size_t)b0 * p.heads + h) * 64) * p.tokens_pad + t0;
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {                             // 8 d-rows x 128 B per store instruction
+                        const int d = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+                        *reinterpret_cast<uint4*>(vrow + (size_t)d * p.tokens_pad + c) = *reinterpret_cast<const uint4*>(vbuf + d * 64 + c);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        const int mm = mblk + mi * 16 + l15;
+                        if (mm < p.M) {
+                            const int b = mm / p.tokens, t = mm % p.tokens;
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    dst[(((size_t)b * p.heads + h) * 64 + ni * 16 + g * 4 + r) * p.tokens_pad + t] =
+                                        from_f32<OutT>(acc[blk * 4 + mi][ni][r]);
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
+
+    float bias_v[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) bias_v[j] = 0.f;
+    if constexpr (EPI == EPI_STD) {
+        if (p.bias && ncol < p.N) {
+#pragma unroll
+            for (int j = 0; j < CPL; j += 4) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + ncol + j);
+                bias_v[j] = bb.x; bias_v[j + 1] = bb.y; bias_v[j + 2] = bb.z; bias_v[j + 3] = bb.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            *reinterpret_cast<f32x4_t*>(ebuf + l15 * ESTRIDE + ni * 16 + g * 4) = acc[mi][ni];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int mbase = mwave + mi * 16;
+        if constexpr (EPI == EPI_STD) {
+            // one store instruction = RPI rows x 64 columns, LPR adjacent lanes per row (full 128-B lines)
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int r = it * RPI + lane / LPR;
+                const int mm = mbase + r;
+                if (mm < p.M && ncol < p.N) {
+                    float v[CPL];
+#pragma unroll
+                    for (int j = 0; j < CPL; j += 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(ebuf + r * ESTRIDE + ccol + j);
+                        v[j] = t.x + bias_v[j]; v[j + 1] = t.y + bias_v[j + 1]; v[j + 2] = t.z + bias_v[j + 2]; v[j + 3] = t.w + bias_v[j + 3];
+                    }
+                    if constexpr (sizeof(OutT) == 4) {
+                        if (p.residual) {
+                            float4 rr;
+                            if constexpr (NPRE > 1) rr = rpre[mi * ITERS + it];      // compile-time index: stays in registers
+                            else rr = *reinterpret_cast<const float4*>(p.residual + (size_t)(mm % p.res_rows) * p.ldr + ncol);
+                            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                        }
+                    }
+                    store_row(reinterpret_cast<OutT*>(p.out) + (size_t)mm * p.ldo + ncol, v);
+                }
+            }
+        } else if constexpr (EPI == EPI_SWIGLU) {
+            // wave columns: [x1 0-15 | x2 0-15 | x1 16-31 | x2 16-31] of 32 hidden columns; lane (erow, q) gates
+            // hidden columns q*8 .. q*8+7
+            const int erow = lane >> 2, m = mbase + erow;
+            if (m < p.M) {
+                const int q = lane & 3;
+                const int c1 = (q >> 1) * 32 + (q & 1) * 8;          // x1 column inside the wave tile
+                const float* e1 = ebuf + erow * ESTRIDE + c1;
+                const float4 a0 = *reinterpret_cast<const float4*>(e1), a1 = *reinterpret_cast<const float4*>(e1 + 4);
+                const float4 g0 = *reinterpret_cast<const float4*>(e1 + 16), g1 = *reinterpret_cast<const float4*>(e1 + 20);
+                const float* b1 = p.bias + nw + c1;
+                const float4 ba0 = *reinterpret_cast<const float4*>(b1), ba1 = *reinterpret_cast<const float4*>(b1 + 4);
+                const float4 bg0 = *reinterpret_cast<const float4*>(b1 + 16), bg1 = *reinterpret_cast<const float4*>(b1 + 20);
+                float h[8];
+                h[0] = silu_mul(a0.x + ba0.x, g0.x + bg0.x, p.fast_math); h[1] = silu_mul(a0.y + ba0.y, g0.y + bg0.y, p.fast_math);
+                h[2] = silu_mul(a0.z + ba0.z, g0.z + bg0.z, p.fast_math); h[3] = silu_mul(a0.w + ba0.w, g0.w + bg0.w, p.fast_math);
+                h[4] = silu_mul(a1.x + ba1.x, g1.x + bg1.x, p.fast_math); h[5] = silu_mul(a1.y + ba1.y, g1.y + bg1.y, p.fast_math);
+                h[6] = silu_mul(a1.z + ba1.z, g1.z + bg1.z, p.fast_math); h[7] = silu_mul(a1.w + ba1.w, g1.w + bg1.w, p.fast_math);
+                OutT* out = reinterpret_cast<OutT*>(p.out) + (size_t)m * p.ldo + (nw >> 1) + q * 8;
+                store4(out, h[0], h[1], h[2], h[3]);
+                store4(out + 4, h[4], h[5], h[6], h[7]);
+            }
+        } else {  // EPI_HEADS, Q or K part: the wave's 64 columns are exactly one head
+            const int part = nw / p.inner;
+            const int h = (nw % p.inner) >> 6;
+            const int kind = p.kinds[part];
+            OutT* dst = reinterpret_cast<OutT*>(p.outs[part]);
+            const int tstride = kind == PMHIP_PART_Q ? p.tokens : p.tokens_pad;
+            const float sc = kind == PMHIP_PART_Q ? p.q_scale : 1.0f;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int r = it * RPI + lane / LPR;
+                const int mm = mbase + r;
+                if (mm < p.M) {
+                    const int b = mm / p.tokens, t = mm % p.tokens;
+                    float v[CPL];
+#pragma unroll
+                    for (int j = 0; j < CPL; j += 4) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(ebuf + r * ESTRIDE + ccol + j);
+                        v[j] = t4.x * sc; v[j + 1] = t4.y * sc; v[j + 2] = t4.z * sc; v[j + 3] = t4.w * sc;
+                    }
+                    store_row(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + ccol, v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next 16 rows overwrite ebuf
+    }
+}
+
+}  // namespace pmgemm

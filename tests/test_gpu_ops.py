@@ -32,6 +32,40 @@ def test_gemm_bias_residual(M, N, K, dtype):
     assert rel_err(n(out2), a @ w.T) < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 512), (16384, 1024, 192), (12288, 4096, 64), (65536, 512, 1408)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_large_tile_kernel(M, N, K, out_dtype):
+    """shapes that take the 256x256 phase-staggered kernel (M, N multiples of 256, >= 192 tiles); K tiles: 8, 3 (odd), 1, 22"""
+    a, w, b = bf16_round(rnd(M, K)), bf16_round(rnd(N, K, scale=K ** -0.5)), rnd(N)
+    out = n(ops.gemm(t(a, torch.bfloat16), t(w, torch.bfloat16), bias=t(b), out_dtype=out_dtype))
+    ref = a @ w.T + b
+    assert rel_err(out, ref) < (2e-5 if out_dtype == torch.float32 else 1e-2), rel_err(out, ref)
+    # every row / column block is touched: compare block-wise maxima too
+    blk = np.abs(out - ref).reshape(M // 256, 256, N // 256, 256).max(axis=(1, 3))
+    assert blk.max() < (1e-3 if out_dtype == torch.float32 else 0.15 * np.abs(ref).max())
+
+
+def test_swiglu_and_heads_large_tile_kernel():
+    M, D, H = 16384, 512, 1368
+    lin = torch.nn.Linear(D, 2 * H)
+    x = bf16_round(rnd(M, D))
+    lin.weight.data = torch.from_numpy(bf16_round(lin.weight.detach().numpy()))
+    w, b = lin.weight.detach().numpy(), lin.bias.detach().numpy()
+    x12 = x @ w.T + b
+    ref = O.silu(x12[:, :H]) * x12[:, H:]
+    w12p, b12p, hp = packing.pack_w12(lin.to(dev()), torch.bfloat16)
+    out = n(ops.gemm_swiglu(t(x, torch.bfloat16), w12p, b12p))
+    assert rel_err(out[:, :H], ref) < 2e-2 and np.all(out[:, H:] == 0)
+    # head-split projection, B=16 images of 1024 tokens, 8 heads
+    B, heads, N = 16, 8, 1024
+    wqkv = bf16_round(rnd(3 * heads * 64, D, scale=D ** -0.5))
+    q, k, vt = ops.gemm_heads(t(x, torch.bfloat16), t(wqkv, torch.bfloat16), heads, N, [ops.PART_Q, ops.PART_K, ops.PART_V], 0.125)
+    full = (x @ wqkv.T).reshape(B, N, 3, heads, 64)
+    assert rel_err(n(q), full[:, :, 0].transpose(0, 2, 1, 3) * 0.125) < 1e-2
+    assert rel_err(n(k), full[:, :, 1].transpose(0, 2, 1, 3)) < 1e-2
+    assert rel_err(n(vt), full[:, :, 2].transpose(0, 2, 3, 1)) < 1e-2
+
+
 def test_gemm_is_transpose_correct_on_asymmetric_data():
     """A = identity-like selector, W asymmetric: catches a swapped (m,n) in the MFMA output mapping."""
     M = N = K = 128
