@@ -204,10 +204,10 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
             bool grow = false;
 #pragma unroll
             for (int qf = 0; qf < QF; ++qf) {
-                float m = fmaxf(fmaxf(fmaxf(s[0][qf][0], s[0][qf][1]), fmaxf(s[0][qf][2], s[0][qf][3])),
-                                fmaxf(fmaxf(s[1][qf][0], s[1][qf][1]), fmaxf(s[1][qf][2], s[1][qf][3])));
-                m = fmaxf(m, __shfl_xor(m, 16, 64));
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float m = vmax3(s[0][qf][0], s[0][qf][1], s[0][qf][2]);
+                m = vmax3(m, s[0][qf][3], s[1][qf][0]);
+                m = vmax3(m, s[1][qf][1], s[1][qf][2]);
+                m = group4_max(vmax2(m, s[1][qf][3]));
                 tmax[qf] = m;
                 grow |= (m - mrun[qf] > kDefer);             // first half-tile: mrun = -inf -> true
             }
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
 #pragma unroll
                 for (int qf = 0; qf < QF; ++qf) {
                     // a half-tile of a ragged last tile may be fully masked (tmax = -inf): keep the max finite
-                    const float mnew = fmaxf(fmaxf(mrun[qf], tmax[qf]), -1e30f);
+                    const float mnew = vmax3(mrun[qf], tmax[qf], -1e30f);
                     const float alpha = EXP2 ? __builtin_amdgcn_exp2f(mrun[qf] - mnew) : expf(mrun[qf] - mnew);
                     mrun[qf] = mnew;
                     lrun[qf] *= alpha;
@@ -273,10 +273,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
     float inv[QF];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {      // cross-lane steps first, outside any divergent region
-        float l = lrun[qf];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        inv[qf] = 1.0f / l;
+        inv[qf] = 1.0f / group4_sum(lrun[qf]);
     }
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {

@@ -146,5 +146,31 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// max without the canonicalising `v_max x,x,x` hipcc puts in front of fmaxf() on MFMA results
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// reductions over the 4 lanes {l, l^16, l^32, l^48} with the gfx950 row / half swaps (no LDS round trip):
+// permlane16_swap(v,v) -> {rows 0,0,2,2 | rows 1,1,3,3}, permlane32_swap(v,v) -> {lo,lo | hi,hi}
+__device__ __forceinline__ float group4_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float m = vmax2(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return vmax2(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float group4_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t dtype_size(int dtype) { return dtype == PMHIP_BF16 ? 2 : 4; }

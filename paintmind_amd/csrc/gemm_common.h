@@ -49,9 +49,11 @@ __device__ __forceinline__ uint4 read_frag(const unsigned char* lds_tile, int ro
     return *reinterpret_cast<const uint4*>(lds_tile + row * ROWB + ((slot ^ (row & 7)) << 4));
 }
 
+// silu(x1) * x2.  fast (bf16 mode): exp2-based exponential and a hardware reciprocal (the result is rounded to
+// bf16 anyway); exact (f32 verify mode): accurate expf and an IEEE divide, like torch's CPU silu.
 __device__ __forceinline__ float silu_mul(float x1, float x2, int fast) {
-    const float e = fast ? __expf(-x1) : expf(-x1);
-    return (x1 / (1.0f + e)) * x2;
+    if (fast) return x1 * __builtin_amdgcn_rcpf(1.0f + __expf(-x1)) * x2;
+    return (x1 / (1.0f + expf(-x1))) * x2;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -184,8 +186,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                 h[4] = silu_mul(a1.x + ba1.x, g1.x + bg1.x, p.fast_math); h[5] = silu_mul(a1.y + ba1.y, g1.y + bg1.y, p.fast_math);
                 h[6] = silu_mul(a1.z + ba1.z, g1.z + bg1.z, p.fast_math); h[7] = silu_mul(a1.w + ba1.w, g1.w + bg1.w, p.fast_math);
                 OutT* out = reinterpret_cast<OutT*>(p.out) + (size_t)m * p.ldo + (nw >> 1) + q * 8;
-                store4(out, h[0], h[1], h[2], h[3]);
-                store4(out + 4, h[4], h[5], h[6], h[7]);
+                if constexpr (sizeof(OutT) == 2) {
+                    store_row(out, h);                               // one 16-byte store
+                } else {
+                    store4(out, h[0], h[1], h[2], h[3]);
+                    store4(out + 4, h[4], h[5], h[6], h[7]);
+                }
             }
         } else {  // EPI_HEADS, Q or K part: the wave's 64 columns are exactly one head
             const int part = nw / p.inner;
