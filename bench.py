@@ -34,6 +34,7 @@ from paintmind_amd.config import ver2cfg  # noqa: E402
 from paintmind_amd.generate import Pipeline  # noqa: E402
 from paintmind_amd.ops import swiglu_hidden  # noqa: E402
 
+USE_GRAPH = True              # the decode loop runs as one replayed hipGraph (the warm-up steps do the capture)
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
@@ -116,7 +117,8 @@ def make_step(workload, model, device, rank, decode_every_step=True):
 
     def step(i):
         ids = torch.full((B, pipe.num_tokens), pipe.mask_token_id, dtype=torch.long, device=device)
-        ids, imgs = eng.generate(vq_eng, ids, ctx, temps, nmask, flags, topk=5, seed=1000 + i, image_base=rank * B)
+        ids, imgs = eng.generate(vq_eng, ids, ctx, temps, nmask, flags, topk=5, seed=1000 + i, image_base=rank * B,
+                                 use_graph=USE_GRAPH)
         return imgs[-1]
     return step
 

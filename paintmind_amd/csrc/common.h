@@ -55,6 +55,22 @@ struct PmTimer {
 extern bool g_pm_timing_on;
 
 // ---------------------------------------------------------------------------------------------
+// per-call scalars of a hipGraph-replayed decode loop (device memory, refreshed before every replay)
+// ---------------------------------------------------------------------------------------------
+constexpr int PM_MAX_STEPS = 128;
+struct PmGenParams {
+    unsigned long long seed;
+    unsigned long long row_base;
+    float temps[PM_MAX_STEPS];
+    int nmask[PM_MAX_STEPS];
+};
+int pm_sample_rows(const float* logits, int ldl, const int64_t* ids_in, int64_t mask_id, int topk, float temperature,
+                   const float* noise, uint64_t seed, uint32_t step, uint64_t row_base, int64_t* pred_out, int64_t* ids_out,
+                   float* score_out, int M, int V, const PmGenParams* gp, pmhip_stream stream);
+int pm_remask(int64_t* ids, const float* scores, int num_mask, int64_t mask_id, int B, int N, const PmGenParams* gp, int step,
+              pmhip_stream stream);
+
+// ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

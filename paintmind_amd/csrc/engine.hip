@@ -364,6 +364,11 @@ extern "C" int pmhip_vqgan_decoder_forward(pmhip_vqgan* h, const float* x, int B
 // ------------------------------------------------------------------------------------------------
 // stage 2: CondTransformer + MaskGIT loop
 // ------------------------------------------------------------------------------------------------
+struct GraphEntry {
+    bool warmed = false;            // one eager pass has sized every workspace buffer
+    hipGraphExec_t exec = nullptr;
+};
+
 struct pmhip_s2 {
     int device = 0, dtype = 0;
     pmhip_s2_cfg cfg{};
@@ -371,6 +376,13 @@ struct pmhip_s2 {
     std::vector<pmhip_layer_weights> layers;
     std::vector<CrossKV> cross;     // per layer, valid after prepare_context
     Workspace ws;
+    std::map<std::string, GraphEntry> graphs;   // captured decode loops, keyed by shape / schedule structure
+    hipStream_t capture_stream = nullptr;       // capture never happens on the caller's stream (it may be the NULL stream)
+    ~pmhip_s2() {
+        for (auto& kv : graphs)
+            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (capture_stream) (void)hipStreamDestroy(capture_stream);
+    }
 };
 
 extern "C" int pmhip_s2_create(pmhip_s2** out, int device, int dtype, const pmhip_s2_cfg* cfg, const pmhip_s2_weights* w) {
@@ -451,7 +463,7 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s) {
 // Pipeline.sample after the context is prepared (generate.py:161-179)
 int sample_step(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, int B, int topk, float temperature, int num_mask,
                 const float* noise, uint64_t seed, uint32_t step, uint64_t image_base, float* img_out, int64_t* pred_out,
-                float* score_out, hipStream_t s) {
+                float* score_out, hipStream_t s, const PmGenParams* gp = nullptr) {
     const auto& c = s2->cfg;
     const int M = B * c.tokens;
     void* tp; float* logits; int64_t* pred; float* score;
@@ -462,15 +474,15 @@ int sample_step(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, int B, int topk, fl
     // ids2tokens: lookup in cat(raw codebook, mask_token) (generate.py:148-157)
     PM_TRY(pmhip_embed_rows(s2->w.tok_table, ids, tp, s2->dtype, 64, M, c.n_embed + 1, c.embed_dim, s));
     PM_TRY(s2_tower(s2, tp, B, logits, s));
-    PM_TRY(pmhip_sample_rows(logits, c.n_embed, ids, (int64_t)c.n_embed, topk, temperature, noise, seed, step,
-                             image_base * (uint64_t)c.tokens, pred, ids, score, M, c.n_embed, s));
+    PM_TRY(pm_sample_rows(logits, c.n_embed, ids, (int64_t)c.n_embed, topk, temperature, noise, seed, step,
+                          image_base * (uint64_t)c.tokens, pred, ids, score, M, c.n_embed, gp, s));
     if (img_out) {
         PM_REQUIRE(vq, "pipeline_sample: img_out requested without a vqgan handle");
         PM_TRY(vq_decode_indices(vq, pred, B, img_out, s));      // decoded from pred at ALL positions (generate.py:165)
     }
     if (pred_out) PM_HIP(hipMemcpyAsync(pred_out, pred, (size_t)M * 8, hipMemcpyDeviceToDevice, s));
     if (score_out) PM_HIP(hipMemcpyAsync(score_out, score, (size_t)M * 4, hipMemcpyDeviceToDevice, s));
-    return pmhip_remask(ids, score, num_mask, (int64_t)c.n_embed, B, c.tokens, s);
+    return pm_remask(ids, score, num_mask, (int64_t)c.n_embed, B, c.tokens, gp, (int)step, s);
 }
 
 }  // namespace
@@ -503,21 +515,80 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
                                        const unsigned char* decode_host, int topk, uint64_t seed, uint64_t image_base,
                                        float* imgs_out, int use_graph, pmhip_stream stream) {
     PM_REQUIRE(s2 && ids && B > 0 && T > 0 && temps_host && nmask_host, "pipeline_generate: bad arguments");
-    (void)use_graph;   // step graphs: reserved (every step is already launch-bound-free at B >= 8)
     hipStream_t s = (hipStream_t)stream;
-    PM_TRY(s2_prepare_context(s2, context, L, B, s));
+    PM_TRY(s2_prepare_context(s2, context, L, B, s));         // context projection + cross K/V: once per loop, eager
     size_t img_elems = 0;
     if (vq) img_elems = (size_t)B * vq->cfg.channels * vq->cfg.image_size * vq->cfg.image_size;
     int n_dec = 0;
-    for (int t = 0; t < T; ++t) {
-        float* img = nullptr;
-        if (decode_host && decode_host[t]) {
-            PM_REQUIRE(vq && imgs_out, "pipeline_generate: decode requested without vqgan/imgs_out");
-            img = imgs_out + (size_t)n_dec * img_elems;
-            ++n_dec;
+    for (int t = 0; t < T; ++t) n_dec += (decode_host && decode_host[t]) ? 1 : 0;
+    PM_REQUIRE(n_dec == 0 || (vq && imgs_out), "pipeline_generate: decode requested without vqgan/imgs_out");
+
+    if (!use_graph || g_pm_timing_on || T > PM_MAX_STEPS) {
+        int d = 0;
+        for (int t = 0; t < T; ++t) {
+            float* img = (decode_host && decode_host[t]) ? imgs_out + (size_t)(d++) * img_elems : nullptr;
+            PM_TRY(sample_step(s2, vq, ids, B, topk, temps_host[t], nmask_host[t], nullptr, seed, (uint32_t)t, image_base, img,
+                               nullptr, nullptr, s));
         }
-        PM_TRY(sample_step(s2, vq, ids, B, topk, temps_host[t], nmask_host[t], nullptr, seed, (uint32_t)t, image_base, img,
-                           nullptr, nullptr, s));
+        return PMHIP_OK;
     }
+
+    // ---- hipGraph path.  The whole T-step loop is ONE graph whose kernels read the per-call scalars
+    // (temperatures, mask counts, seed, row base) from a device parameter block and whose ids / image pointers are
+    // handle-owned buffers, so the same executable graph serves every call with this structure.
+    const size_t ids_bytes = (size_t)B * s2->cfg.tokens * 8;
+    int64_t* gids; float* gimgs; PmGenParams* gparams;
+    WS(s2->ws, "gen.ids", ids_bytes, gids);
+    WS(s2->ws, "gen.imgs", (size_t)(n_dec ? n_dec : 1) * img_elems * 4 + 16, gimgs);
+    WS(s2->ws, "gen.params", sizeof(PmGenParams), gparams);
+    PmGenParams hp{};
+    hp.seed = seed;
+    hp.row_base = image_base * (uint64_t)s2->cfg.tokens;
+    for (int t = 0; t < T; ++t) { hp.temps[t] = temps_host[t]; hp.nmask[t] = nmask_host[t]; }
+    PM_HIP(hipMemcpyAsync(gparams, &hp, sizeof hp, hipMemcpyHostToDevice, s));       // pageable source: staged synchronously
+    PM_HIP(hipMemcpyAsync(gids, ids, ids_bytes, hipMemcpyDeviceToDevice, s));
+
+    std::string key = "B" + std::to_string(B) + "T" + std::to_string(T) + "k" + std::to_string(topk) + "L" +
+                      std::to_string(context ? L : 0) + "v" + std::to_string((size_t)vq) + "d";
+    for (int t = 0; t < T; ++t) key += (decode_host && decode_host[t]) ? '1' : '0';
+    GraphEntry& ge = s2->graphs[key];
+
+    auto run_steps = [&](hipStream_t on) -> int {
+        int d = 0;
+        for (int t = 0; t < T; ++t) {
+            float* img = (decode_host && decode_host[t]) ? gimgs + (size_t)(d++) * img_elems : nullptr;
+            PM_TRY(sample_step(s2, vq, gids, B, topk, 0.f, 0, nullptr, 0, (uint32_t)t, 0, img, nullptr, nullptr, on, gparams));
+        }
+        return PMHIP_OK;
+    };
+
+    if (!ge.warmed) {
+        PM_TRY(run_steps(s));                                  // eager once: sizes every workspace buffer
+        ge.warmed = true;
+    } else {
+        if (!ge.exec) {
+            if (!s2->capture_stream) PM_HIP(hipStreamCreateWithFlags(&s2->capture_stream, hipStreamNonBlocking));
+            hipStream_t cap = s2->capture_stream;
+            hipGraph_t graph = nullptr;
+            s2->ws.frozen = true;
+            if (vq) vq->ws.frozen = true;
+            hipError_t rc = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+            int step_rc = PMHIP_OK;
+            if (rc == hipSuccess) {
+                step_rc = run_steps(cap);                      // records only: nothing executes during capture
+                rc = hipStreamEndCapture(cap, &graph);
+            }
+            s2->ws.frozen = false;
+            if (vq) vq->ws.frozen = false;
+            if (step_rc != PMHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return step_rc; }
+            PM_HIP(rc);
+            rc = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            PM_HIP(rc);
+        }
+        PM_HIP(hipGraphLaunch(ge.exec, s));
+    }
+    PM_HIP(hipMemcpyAsync(ids, gids, ids_bytes, hipMemcpyDeviceToDevice, s));
+    if (n_dec) PM_HIP(hipMemcpyAsync(imgs_out, gimgs, (size_t)n_dec * img_elems * 4, hipMemcpyDeviceToDevice, s));
     return PMHIP_OK;
 }

@@ -58,10 +58,16 @@ template <int NV4>
 __global__ __launch_bounds__(THREADS) void sample_rows_kernel(
     const float* __restrict__ logits, int ldl, const int64_t* __restrict__ ids_in, int64_t mask_id, int topk,
     float temperature, const float* __restrict__ noise, uint64_t seed, uint32_t step, uint64_t row_base,
-    int64_t* __restrict__ pred_out, int64_t* __restrict__ ids_out, float* __restrict__ score_out, int M, int V) {
+    int64_t* __restrict__ pred_out, int64_t* __restrict__ ids_out, float* __restrict__ score_out, int M, int V,
+    const PmGenParams* __restrict__ gp) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
     if (row >= M) return;                                  // whole wave exits together
+    if (gp) {                                              // graph replay: per-call scalars live in device memory
+        temperature = gp->temps[step];
+        seed = gp->seed;
+        row_base = gp->row_base;
+    }
     const float* lrow = logits + (size_t)row * ldl;
 
     float4 x[NV4];
@@ -150,7 +156,9 @@ __device__ __forceinline__ uint32_t orderable(float f) {
 }
 
 __global__ __launch_bounds__(THREADS) void remask_kernel(int64_t* __restrict__ ids, const float* __restrict__ scores,
-                                                         int num_mask, int64_t mask_id, int N, int Npow2) {
+                                                         int num_mask, int64_t mask_id, int N, int Npow2,
+                                                         const PmGenParams* __restrict__ gp, int step) {
+    if (gp) num_mask = gp->nmask[step];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
     const int b = blockIdx.x;
@@ -182,10 +190,9 @@ __global__ __launch_bounds__(THREADS) void remask_kernel(int64_t* __restrict__ i
 
 }  // namespace
 
-extern "C" int pmhip_sample_rows(const float* logits, int ldl, const int64_t* ids_in, int64_t mask_id, int topk,
-                                 float temperature, const float* noise, uint64_t seed, uint32_t step,
-                                 uint64_t row_base, int64_t* pred_out, int64_t* ids_out, float* score_out, int M,
-                                 int V, pmhip_stream stream) {
+int pm_sample_rows(const float* logits, int ldl, const int64_t* ids_in, int64_t mask_id, int topk, float temperature,
+                   const float* noise, uint64_t seed, uint32_t step, uint64_t row_base, int64_t* pred_out, int64_t* ids_out,
+                   float* score_out, int M, int V, const PmGenParams* gp, pmhip_stream stream) {
     PM_REQUIRE(logits && ids_in && ids_out, "sample_rows: null pointer");
     PM_REQUIRE(M > 0 && V > 0 && V % 4 == 0 && ldl % 4 == 0 && ldl >= V, "sample_rows: bad shape M=%d V=%d ldl=%d", M, V, ldl);
     PM_REQUIRE(topk >= 1 && topk <= 64 && topk <= V, "sample_rows: topk=%d must be in [1, min(64,V)]", topk);
@@ -195,7 +202,7 @@ extern "C" int pmhip_sample_rows(const float* logits, int ldl, const int64_t* id
     PmTimer tm(FAM_SAMPLE, s);
 #define PM_SAMPLE(NV4)                                                                                              \
     hipLaunchKernelGGL((sample_rows_kernel<NV4>), grid, block, 0, s, logits, ldl, ids_in, mask_id, topk, temperature, \
-                       noise, seed, step, row_base, pred_out, ids_out, score_out, M, V)
+                       noise, seed, step, row_base, pred_out, ids_out, score_out, M, V, gp)
     if (V <= 256) PM_SAMPLE(1);
     else if (V <= 1024) PM_SAMPLE(4);
     else if (V <= 8192) PM_SAMPLE(32);
@@ -205,15 +212,28 @@ extern "C" int pmhip_sample_rows(const float* logits, int ldl, const int64_t* id
     return PMHIP_OK;
 }
 
-extern "C" int pmhip_remask(int64_t* ids, const float* scores, int num_mask, int64_t mask_id, int B, int N,
-                            pmhip_stream stream) {
+extern "C" int pmhip_sample_rows(const float* logits, int ldl, const int64_t* ids_in, int64_t mask_id, int topk,
+                                 float temperature, const float* noise, uint64_t seed, uint32_t step,
+                                 uint64_t row_base, int64_t* pred_out, int64_t* ids_out, float* score_out, int M,
+                                 int V, pmhip_stream stream) {
+    return pm_sample_rows(logits, ldl, ids_in, mask_id, topk, temperature, noise, seed, step, row_base, pred_out, ids_out,
+                          score_out, M, V, nullptr, stream);
+}
+
+int pm_remask(int64_t* ids, const float* scores, int num_mask, int64_t mask_id, int B, int N, const PmGenParams* gp, int step,
+              pmhip_stream stream) {
     PM_REQUIRE(ids && scores, "remask: null pointer");
     PM_REQUIRE(B > 0 && N > 0 && N <= 4096, "remask: bad shape B=%d N=%d (N <= 4096)", B, N);
     int np2 = 1;
     while (np2 < N) np2 <<= 1;
     hipStream_t s = (hipStream_t)stream;
     PmTimer tm(FAM_SAMPLE, s);
-    hipLaunchKernelGGL(remask_kernel, dim3(B), dim3(THREADS), (size_t)np2 * 8, s, ids, scores, num_mask, mask_id, N, np2);
+    hipLaunchKernelGGL(remask_kernel, dim3(B), dim3(THREADS), (size_t)np2 * 8, s, ids, scores, num_mask, mask_id, N, np2, gp, step);
     PM_HIP(hipGetLastError());
     return PMHIP_OK;
+}
+
+extern "C" int pmhip_remask(int64_t* ids, const float* scores, int num_mask, int64_t mask_id, int B, int N,
+                            pmhip_stream stream) {
+    return pm_remask(ids, scores, num_mask, mask_id, B, N, nullptr, 0, stream);
 }

@@ -1,0 +1,55 @@
+"""Multi-GPU generation: independent images, one process per GPU, no collective in the data path.
+
+The reference has no multi-GPU inference; this is the new sharded path that
+BASELINE.json asks for.  A global prompt list is split contiguously over ranks, every rank decodes its
+own images with the sampling RNG keyed by the GLOBAL image index (so the result does not depend on the
+number of ranks), and the finished images are gathered once with torch.distributed (RCCL on ROCm,
+gloo in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world_size):
+    """contiguous, balanced split: the first (n % world) ranks get one extra item"""
+    base, extra = divmod(n_items, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def gather_images(local, counts, dst=0, group=None):
+    """Gather per-rank image tensors [n_r, ...] (ragged in dim 0) onto rank `dst`; returns the concatenation
+    there and None elsewhere.  One collective per call; tensors are padded to the largest shard."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    nmax = max(counts)
+    pad = local
+    if local.shape[0] < nmax:
+        pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad.contiguous(), bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def generate_sharded(pipe, text, seed, group=None, dst=0, **kwargs):
+    """Pipeline.generate over a prompt list sharded across the process group.
+
+    Returns on rank `dst` the same list-of-tensors structure the single-process call returns for the full
+    prompt list (bit-identical for the same seed); other ranks get None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = [shard_range(len(text), r, world)[1] - shard_range(len(text), r, world)[0] for r in range(world)]
+    lo, hi = shard_range(len(text), rank, world)
+    tm = getattr(pipe, "text_model", None)
+    if tm is not None and hasattr(tm, "base_index"):
+        tm.base_index = lo                                   # synthetic text features are keyed by global index
+    imgs = pipe.generate(text[lo:hi], seed=seed, image_base=lo, keep_on_device=True, **kwargs) if hi > lo else []
+    n_out = torch.tensor([len(imgs)], dtype=torch.int64, device=imgs[0].device if imgs else "cpu")
+    out = []
+    for t in range(int(n_out.item())):
+        g = gather_images(imgs[t], counts, dst=dst, group=group)
+        out.append(g.cpu() if g is not None else None)
+    return out if rank == dst else None

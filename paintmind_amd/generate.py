@@ -147,7 +147,7 @@ class Pipeline(nn.Module):
 
     @torch.no_grad()
     def generate(self, text, timesteps=18, temperature=1.0, topk=5, save_interval=2, seed=None, image_base=0,
-                 return_ids=False, keep_on_device=False):
+                 return_ids=False, keep_on_device=False, use_graph=False):
         """Full decode loop (generate.py:183-198): list of (B,3,H,W) CPU tensors for steps % save_interval == 0."""
         B = len(text)
         context = self.text_model(text)
@@ -157,7 +157,10 @@ class Pipeline(nn.Module):
         ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
         temps, nmask = self._schedule(timesteps, temperature)
         flags = [step % save_interval == 0 for step in range(timesteps)]
-        ids, imgs = eng.generate(self.vqgan.engine(), ids, context, temps, nmask, flags, topk, seed=seed, image_base=image_base)
+        # use_graph: the T-step loop is captured into one hipGraph (first call eager, second call captures, later
+        # calls replay); per-call scalars (seed, schedule values) are read from device memory, so one graph serves all
+        ids, imgs = eng.generate(self.vqgan.engine(), ids, context, temps, nmask, flags, topk, seed=seed, image_base=image_base,
+                                 use_graph=use_graph)
         out = [] if imgs is None else [im if keep_on_device else im.cpu() for im in imgs]
         return (out, ids) if return_ids else out
 
