@@ -34,7 +34,7 @@ from paintmind_amd.config import ver2cfg  # noqa: E402
 from paintmind_amd.generate import Pipeline  # noqa: E402
 from paintmind_amd.ops import swiglu_hidden  # noqa: E402
 
-USE_GRAPH = True              # the decode loop runs as one replayed hipGraph (the warm-up steps do the capture)
+USE_GRAPH = os.environ.get("PM_BENCH_NO_GRAPH", "0") != "1"   # decode loop = one replayed hipGraph (captured during warm-up)
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
@@ -198,6 +198,21 @@ def cpu_baseline(workload):
                       f"of the reference on {cores} threads"}
 
 
+def pmc_traffic(workload, dtype):
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of this same command, read side doubled per the gfx950 correction).
+    Only valid for the configuration it was collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if workload != "maskgit-uncond-12L-d512-T8" or dtype != "bf16" or not os.path.exists(path):
+        return None
+    try:
+        fam = json.load(open(path))["families"]["gemm"]
+        return {"hbm_bytes_per_launch": round(fam["hbm_bytes_per_launch"]), "read": round(fam["hbm_read_bytes_per_launch"]),
+                "write": round(fam["hbm_write_bytes_per_launch"]), "source": "profiles/r01_pmc_traffic.json"}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -288,8 +303,9 @@ def main():
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         ach = gf / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
         result["roofline"] = {
-            "kernel": "gemm_nt_kernel (all GEMM launches of one step)", "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launches": n_g,
+            "kernel": "GEMM family (gemm256_kernel + gemm_nt_kernel, all launches of one step)", "bound": "mfma",
+            "achieved": round(ach, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(args.workload, args.dtype), "launches": n_g,
             "avg_launch_ms": round(ms_g / max(n_g, 1), 4), "algorithmic_gflop_per_launch": round(gf / max(n_g, 1) / 1e9, 2)}
         n_a, ms_a = fam["attention"]
         n_s, ms_s = fam["sample"]

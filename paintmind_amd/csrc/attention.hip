@@ -110,7 +110,7 @@ __device__ __forceinline__ void zero_ragged_v(unsigned char* Vl, int kv0, int Nk
 template <typename T, bool EXP2, int QF>
 __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restrict__ Q, const T* __restrict__ Kp,
                                                             const T* __restrict__ Vt, T* __restrict__ out,
-                                                            int ldo, int heads, int Nq, int Nkv, int Nkv_pad) {
+                                                            int ldo, int heads, int Nq, int Nkv, int Nkv_pad, int nqb) {
     using C = AttnCfg<T>;
     constexpr int TILE_BYTES = KT * C::ROWB;
     constexpr int STAGE_BYTES = 2 * TILE_BYTES;              // K tile + V^T tile
@@ -121,9 +121,22 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.y;
+    // 1-D grid.  Workgroup L runs on XCD L % 8 (private 4 MiB L2): give all query blocks of one (batch, head) the
+    // same L % 8 so its K / V^T (256 KiB in bf16) are fetched from HBM once and re-read from that XCD's L2.
+    int bh, qblk;
+    {
+        const int L = blockIdx.x, total_bh = gridDim.x / nqb;
+        if ((total_bh & 7) == 0) {
+            const int slot = L >> 3;
+            qblk = slot % nqb;
+            bh = (slot / nqb) * 8 + (L & 7);
+        } else {
+            qblk = L % nqb;
+            bh = L / nqb;
+        }
+    }
     const int b = bh / heads, h = bh % heads;
-    const int q0 = blockIdx.x * (4 * QF * 16) + wave * (QF * 16);
+    const int q0 = qblk * (4 * QF * 16) + wave * (QF * 16);
 
     const T* Qbh = Q + (size_t)bh * Nq * DH;
     const unsigned char* Kbh = reinterpret_cast<const unsigned char*>(Kp + (size_t)bh * Nkv_pad * DH);
@@ -302,21 +315,23 @@ extern "C" int pmhip_attention(int dtype, const void* Q, const void* K, const vo
     dim3 block(THREADS);
     PmTimer tm(FAM_ATTENTION, s);
     if (dtype == PMHIP_F32) {
-        dim3 grid(ceil_div(Nq, 4 * 2 * 16), B * heads);
+        const int nqb = ceil_div(Nq, 4 * 2 * 16);
+        dim3 grid(nqb * B * heads);
         if (use_exp2)
             hipLaunchKernelGGL((attention_kernel<float, true, 2>), grid, block, 0, s, (const float*)Q, (const float*)K,
-                               (const float*)Vt, (float*)out, ldo, heads, Nq, Nkv, Nkv_pad);
+                               (const float*)Vt, (float*)out, ldo, heads, Nq, Nkv, Nkv_pad, nqb);
         else
             hipLaunchKernelGGL((attention_kernel<float, false, 2>), grid, block, 0, s, (const float*)Q, (const float*)K,
-                               (const float*)Vt, (float*)out, ldo, heads, Nq, Nkv, Nkv_pad);
+                               (const float*)Vt, (float*)out, ldo, heads, Nq, Nkv, Nkv_pad, nqb);
     } else {
-        dim3 grid(ceil_div(Nq, 4 * 4 * 16), B * heads);
+        const int nqb = ceil_div(Nq, 4 * 4 * 16);
+        dim3 grid(nqb * B * heads);
         if (use_exp2)
             hipLaunchKernelGGL((attention_kernel<bf16_t, true, 4>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K,
-                               (const bf16_t*)Vt, (bf16_t*)out, ldo, heads, Nq, Nkv, Nkv_pad);
+                               (const bf16_t*)Vt, (bf16_t*)out, ldo, heads, Nq, Nkv, Nkv_pad, nqb);
         else
             hipLaunchKernelGGL((attention_kernel<bf16_t, false, 4>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K,
-                               (const bf16_t*)Vt, (bf16_t*)out, ldo, heads, Nq, Nkv, Nkv_pad);
+                               (const bf16_t*)Vt, (bf16_t*)out, ldo, heads, Nq, Nkv, Nkv_pad, nqb);
     }
     PM_HIP(hipGetLastError());
     return PMHIP_OK;

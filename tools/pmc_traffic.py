@@ -1,0 +1,55 @@
+"""Aggregate rocprofv3 FETCH_SIZE / WRITE_SIZE passes into per-kernel-family HBM traffic.
+
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are reported in KiB-like
+units of 1024 B (bytes = value * 1024... rocprofv3 reports them in kilobytes); on gfx950 FETCH_SIZE counts a wide
+coalesced streaming read at HALF its bytes (128-B requests tallied as 64 B), so the read side is doubled.
+WRITE_SIZE is uncalibrated in that guide and taken as is."""
+import collections
+import csv
+import json
+import sys
+
+
+def family(name):
+    if "gemm256" in name or "gemm_nt" in name:
+        return "gemm"
+    if "attention" in name:
+        return "attention"
+    if "layernorm" in name:
+        return "layernorm"
+    if "sample_rows" in name or "remask" in name:
+        return "sample"
+    return None
+
+
+def collect(d, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f"{d}/p_counter_collection.csv")):
+        if r["Counter_Name"] != counter:
+            continue
+        f = family(r["Kernel_Name"])
+        if f:
+            agg[f][0] += 1
+            agg[f][1] += float(r["Counter_Value"])
+    return agg
+
+
+def main(fetch_dir, write_dir, out):
+    fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    res = {}
+    for f in fe:
+        n = fe[f][0]
+        read_b = fe[f][1] * 1024 * 2          # gfx950: FETCH_SIZE under-counts wide coalesced reads by 2x
+        write_b = wr[f][1] * 1024 if f in wr else 0.0
+        res[f] = {"launches_profiled": n, "hbm_read_bytes_per_launch": read_b / n, "hbm_write_bytes_per_launch": write_b / max(wr[f][0], 1),
+                  "hbm_bytes_per_launch": read_b / n + write_b / max(wr[f][0], 1)}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 1 (eager loop)",
+               "correction": "read bytes = FETCH_SIZE*1024*2 (gfx950 half-count), write bytes = WRITE_SIZE*1024", "families": res},
+              open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
