@@ -35,6 +35,7 @@ from paintmind_amd.generate import Pipeline  # noqa: E402
 from paintmind_amd.ops import swiglu_hidden  # noqa: E402
 
 USE_GRAPH = os.environ.get("PM_BENCH_NO_GRAPH", "0") != "1"   # decode loop = one replayed hipGraph (captured during warm-up)
+STREAMS = int(os.environ.get("PM_BENCH_STREAMS", "3"))   # concurrent micro-batches per GPU (1 = one stream)
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
@@ -107,19 +108,23 @@ def make_step(workload, model, device, rank, decode_every_step=True):
             return model.decode(z)
         return step
     pipe = model
-    eng, vq_eng = pipe.engine(), pipe.vqgan.engine()
     ctx = None
     if L is not None:
         g = torch.Generator().manual_seed(1234 + rank)
         ctx = torch.randn(B, L, ver2cfg[cfg_name]["context_dim"], generator=g).to(device)
-    temps, nmask = pipe._schedule(T, 1.0)
     flags = [True] * T if decode_every_step else [t == T - 1 for t in range(T)]
 
-    def step(i):
-        ids = torch.full((B, pipe.num_tokens), pipe.mask_token_id, dtype=torch.long, device=device)
-        ids, imgs = eng.generate(vq_eng, ids, ctx, temps, nmask, flags, topk=5, seed=1000 + i, image_base=rank * B,
-                                 use_graph=USE_GRAPH)
+    def step(i, join=True, streams=None):
+        STREAMS = globals()["STREAMS"] if streams is None else streams
+        # join=False (single-GPU timed loop): the micro-batch lanes are not joined between steps, so consecutive
+        # steps pipeline across lanes; the caller joins once before the closing synchronize
+        if STREAMS > 1 and not join:
+            return pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=1000 + i, image_base=rank * B, use_graph=USE_GRAPH,
+                                     streams=STREAMS, join=False, wait_current=False)
+        ids, imgs = pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=1000 + i, image_base=rank * B, use_graph=USE_GRAPH,
+                                      streams=STREAMS, wait_current=False)
         return imgs[-1]
+    step.joins = True
     return step
 
 
@@ -233,7 +238,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PM_BENCH_FORCE_DIST") == "1":      # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -258,9 +263,13 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
+    free_running = dist is None and getattr(step, "joins", False) and STREAMS > 1
     t0 = time.perf_counter()
     for i in range(args.steps):
-        gather(step(args.warmup + i))
+        if free_running:
+            step(args.warmup + i, join=False)     # lanes keep their own stream order; device-wide sync below joins them
+        else:
+            gather(step(args.warmup + i))
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
@@ -279,7 +288,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic (seeded random-init weights, all-masked start ids, Philox sampling noise)",
         "config": {"workload": args.workload, "batch_per_gpu": B, "timesteps": WORKLOADS[args.workload][2],
                    "topk": 5, "decode": "final step only" if args.final_decode_only else "every step (reference-equivalent work)",
-                   "parallelism": f"dp{world} (independent images, no data-path collective)"},
+                   "parallelism": f"dp{world} (independent images, no data-path collective)",
+                   "hip_graph": bool(USE_GRAPH), "concurrent_micro_batches": STREAMS},
         "images_per_s_per_gpu": round(value / world, 3),
     }
 
@@ -295,7 +305,10 @@ def main():
             af -= B * (T - 1) * ad
         ops.timing_reset()
         ops.timing_enable(True)
-        step(10_000)
+        if WORKLOADS[args.workload][0] is None:
+            step(10_000)
+        else:
+            step(10_000, streams=1)                    # timing on => one stream, eager loop, every launch bracketed
         torch.cuda.synchronize(device)
         ops.timing_enable(False)
         fam = {f: ops.timing_get(f) for f in ("gemm", "attention", "layernorm", "sample", "vq", "rowops")}

@@ -113,6 +113,15 @@ class VqganEngine:
         except Exception:
             pass
 
+    def clone(self):
+        """a second native handle (own workspace, own graphs) over the SAME packed weights: one per concurrent stream"""
+        other = object.__new__(VqganEngine)
+        other.__dict__.update({k: v for k, v in self.__dict__.items() if k != "handle"})
+        other.handle = C.c_void_p()
+        check(self.lib.pmhip_vqgan_create(C.byref(other.handle), self.device.index or 0, pm_dtype(self.dtype), C.byref(self.cfg),
+                                          C.byref(self.weights)), "pmhip_vqgan_create")
+        return other
+
     # -- entry points -------------------------------------------------------------------------------
     def _img(self, img):
         if not img.is_cuda:
@@ -220,6 +229,15 @@ class S2Engine:
                 self.handle = None
         except Exception:
             pass
+
+    def clone(self):
+        """a second native handle (own workspace, own graphs) over the SAME packed weights: one per concurrent stream"""
+        other = object.__new__(S2Engine)
+        other.__dict__.update({k: v for k, v in self.__dict__.items() if k != "handle"})
+        other.handle = C.c_void_p()
+        check(self.lib.pmhip_s2_create(C.byref(other.handle), self.device.index or 0, pm_dtype(self.dtype), C.byref(self.cfg),
+                                       C.byref(self.weights)), "pmhip_s2_create")
+        return other
 
     def _ctx(self, context):
         if context is None:

@@ -146,21 +146,83 @@ class Pipeline(nn.Module):
         return temps, nmask
 
     @torch.no_grad()
+    def _lanes(self, k):
+        """k (engine pair, stream) lanes for concurrent micro-batches; lane 0 is the primary engines"""
+        eng, vq = self.engine(), self.vqgan.engine()
+        cache = getattr(self, "_lane_cache", None)
+        if cache is None or cache[0] is not eng or cache[1] is not vq:
+            cache = (eng, vq, [(eng, vq, torch.cuda.Stream(device=eng.device))])
+            self._lane_cache = cache
+        lanes = cache[2]
+        while len(lanes) < k:
+            lanes.append((eng.clone(), vq.clone(), torch.cuda.Stream(device=eng.device)))
+        return lanes[:k]
+
+    def generate_ids(self, context, B, timesteps, temperature, topk, decode_flags, seed, image_base=0, use_graph=False, streams=1,
+                     join=True, wait_current=True):
+        """The decode loop on device tensors: returns (ids [B,N], imgs [n_decoded,B,C,H,W] or None).
+
+        streams > 1: the batch is cut into that many contiguous micro-batches that run CONCURRENTLY on separate HIP
+        streams (own native handle + workspace each, same weights): memory-bound kernels of one micro-batch overlap
+        the MFMA-bound kernels of another.  The sampling RNG is keyed by the global image index, so the result is
+        identical to streams=1.
+        join=False returns the per-lane results [(ids, imgs, stream), ...] without making the current stream wait (the
+        caller joins); wait_current=False does not make the lanes wait for work already queued on the current stream
+        (only valid when `context` is None or was produced before the lanes last synchronised with it)."""
+        eng = self.engine()
+        temps, nmask = self._schedule(timesteps, temperature)
+        streams = max(1, min(int(streams), B))
+        if streams == 1:
+            ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
+            return eng.generate(self.vqgan.engine(), ids, context, temps, nmask, decode_flags, topk, seed=seed,
+                                image_base=image_base, use_graph=use_graph)
+        from .dist import shard_range
+        cur = torch.cuda.current_stream(eng.device)
+        if wait_current:
+            ready = torch.cuda.Event()
+            ready.record(cur)
+        parts = []
+        for i, (e, v, st) in enumerate(self._lanes(streams)):
+            lo, hi = shard_range(B, i, streams)
+            if wait_current:
+                st.wait_event(ready)
+            with torch.cuda.stream(st):
+                ids = torch.full((hi - lo, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
+                c = None if context is None else context[lo:hi].contiguous()
+                ids, imgs = e.generate(v, ids, c, temps, nmask, decode_flags, topk, seed=seed, image_base=image_base + lo,
+                                       use_graph=use_graph)
+                parts.append((ids, imgs, st))
+        if not join:
+            return parts
+        return self.join_lanes(parts)
+
+    def join_lanes(self, parts):
+        """make the current stream wait for the lanes and concatenate their results"""
+        cur = torch.cuda.current_stream(parts[0][0].device)
+        for ids, imgs, st in parts:
+            cur.wait_stream(st)
+            ids.record_stream(cur)                    # allocated on the lane's stream, consumed on the current one
+            if imgs is not None:
+                imgs.record_stream(cur)
+        ids = torch.cat([p[0] for p in parts], dim=0)
+        imgs = None if parts[0][1] is None else torch.cat([p[1] for p in parts], dim=1)
+        return ids, imgs
+
     def generate(self, text, timesteps=18, temperature=1.0, topk=5, save_interval=2, seed=None, image_base=0,
-                 return_ids=False, keep_on_device=False, use_graph=False):
+                 return_ids=False, keep_on_device=False, use_graph=False, streams=1):
         """Full decode loop (generate.py:183-198): list of (B,3,H,W) CPU tensors for steps % save_interval == 0."""
         B = len(text)
         context = self.text_model(text)
         eng = self.engine()
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # governed by torch.manual_seed like the reference
-        ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
-        temps, nmask = self._schedule(timesteps, temperature)
         flags = [step % save_interval == 0 for step in range(timesteps)]
         # use_graph: the T-step loop is captured into one hipGraph (first call eager, second call captures, later
         # calls replay); per-call scalars (seed, schedule values) are read from device memory, so one graph serves all
-        ids, imgs = eng.generate(self.vqgan.engine(), ids, context, temps, nmask, flags, topk, seed=seed, image_base=image_base,
-                                 use_graph=use_graph)
+        if context is not None:
+            context = context.to(eng.device)
+        ids, imgs = self.generate_ids(context, B, timesteps, temperature, topk, flags, seed, image_base=image_base,
+                                      use_graph=use_graph, streams=streams)
         out = [] if imgs is None else [im if keep_on_device else im.cpu() for im in imgs]
         return (out, ids) if return_ids else out
 

@@ -166,6 +166,17 @@ def test_generate_hipgraph_replay_is_bit_identical(tiny_pipe):
     assert all(torch.equal(x, y) and torch.equal(x, z) for x, y, z in zip(a, b, c))
 
 
+def test_generate_concurrent_micro_batches_match_single_stream(tiny_pipe):
+    pipe, p, d = tiny_pipe
+    texts = ["a", "b", "c", "d", "e"]
+    one = pipe.generate(texts, timesteps=5, topk=3, save_interval=1, seed=11, return_ids=True)
+    for k in (2, 3, 5):
+        for graph in (False, True, True):
+            many = pipe.generate(texts, timesteps=5, topk=3, save_interval=1, seed=11, return_ids=True, streams=k, use_graph=graph)
+            assert torch.equal(many[1], one[1]), (k, graph)
+            assert all(torch.equal(a, b) for a, b in zip(many[0], one[0])), (k, graph)
+
+
 def test_inpaint_outpaint_run(tiny_pipe):
     """The reference's inpaint/outpaint crash on float ids (api.json: inpaint_runs == false); this build
     implements the evident intent.  Unmasked tokens must survive, the image must be finite."""
