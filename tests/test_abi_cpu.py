@@ -96,3 +96,30 @@ def test_packing_roundtrip():
     assert torch.equal(w12p[32:48], w[16:32]) and torch.equal(w12p[160 + 16:160 + 24], w[88 + 80:88 + 88])
     assert torch.count_nonzero(w12p[160 + 8:160 + 16]) == 0 and torch.count_nonzero(w12p[192:]) == 0
     assert torch.equal(b12p[16:32], lin.bias.detach()[88:104])
+
+
+def test_transforms_without_torchvision():
+    """stage1/2_transform restated with PIL + torch (reference utils/transform.py:7-34): range, geometry, RNG order"""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 256, (300, 400, 3), dtype=np.uint8))
+    x = pm.stage1_transform(is_train=False, scale=0.8)(img)
+    assert x.shape == (3, 256, 256) and x.dtype == torch.float32 and -1.0 <= float(x.min()) and float(x.max()) <= 1.0
+    # evaluation = bicubic resize to 320 then the central 256 window
+    ref = np.asarray(img.resize((320, 320), Image.BICUBIC).crop((32, 32, 288, 288)), dtype=np.float32) / 255
+    assert torch.allclose(x, torch.from_numpy(ref).permute(2, 0, 1) * 2 - 1)
+    torch.manual_seed(5)
+    a = pm.stage1_transform(is_train=True)(img)
+    torch.manual_seed(5)
+    b = pm.stage1_transform(is_train=True)(img)
+    assert torch.equal(a, b)
+    torch.manual_seed(5)
+    top, left, coin = int(torch.randint(0, 65, (1,))), int(torch.randint(0, 65, (1,))), bool(torch.rand(1) < 0.5)
+    crop = img.resize((320, 320), Image.BICUBIC).crop((left, top, left + 256, top + 256))
+    if coin:
+        crop = crop.transpose(Image.FLIP_LEFT_RIGHT)
+    assert torch.allclose(a, torch.from_numpy(np.asarray(crop, dtype=np.float32) / 255).permute(2, 0, 1) * 2 - 1)
+    assert pm.stage2_transform(img_size=128, is_train=False)(img).shape == (3, 128, 128)
+    from paintmind_amd.reconstruct import restore
+    assert restore(x).size == (256, 256)

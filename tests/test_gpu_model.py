@@ -177,6 +177,20 @@ def test_generate_concurrent_micro_batches_match_single_stream(tiny_pipe):
             assert all(torch.equal(a, b) for a, b in zip(many[0], one[0])), (k, graph)
 
 
+def test_reconstruction_figure(tmp_path):
+    """reference reconstruct.py:23-52: file -> transform -> encode -> decode -> 512x256 side-by-side figure"""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    path = str(tmp_path / "in.png")
+    Image.fromarray(rng.integers(0, 256, (300, 300, 3), dtype=np.uint8)).save(path)
+    torch.manual_seed(0)
+    fig = pm.reconstruction(path, model_name="vit-s-vqgan", pretrained=False, device="cuda")
+    assert fig.size == (512, 256)
+    left = np.asarray(fig.crop((0, 20, 256, 256)), dtype=np.int32)
+    ref = np.asarray(Image.open(path).convert("RGB").resize((320, 320), Image.BICUBIC).crop((32, 32, 288, 288)).crop((0, 20, 256, 256)), dtype=np.int32)
+    assert np.abs(left - ref).max() <= 1          # the left half is the (transformed) input
+
+
 def test_inpaint_outpaint_run(tiny_pipe):
     """The reference's inpaint/outpaint crash on float ids (api.json: inpaint_runs == false); this build
     implements the evident intent.  Unmasked tokens must survive, the image must be finite."""
