@@ -329,6 +329,17 @@ def main():
         if ms_s > 0 and sample_bytes:
             result["kernel_families"]["sample"]["logits_GBps"] = round(sample_bytes / (ms_s * 1e-3) / 1e9, 1)
         result["end_to_end_tflops_per_gpu"] = round((gf + af) / (ms_per_step * 1e-3) / 1e12, 2)
+    if rank == 0 and world == 1 and WORKLOADS[args.workload][0] is not None and not args.final_decode_only:
+        # secondary number (NOT the headline): same loop, but only the image of the last step is decoded
+        alt = make_step(args.workload, model, device, rank, decode_every_step=False)
+        for i in range(3):
+            alt(i)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for i in range(3):
+            alt(3 + i, join=False) if STREAMS > 1 else alt(3 + i)
+        torch.cuda.synchronize(device)
+        result["extra"] = {"final_decode_only_images_per_s": round(3 * B / (time.perf_counter() - t1), 2)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
         // and the softmax VALU of one half overlaps the MFMAs of the other across the co-resident waves.
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
+            if (kv0 + 32 * pc >= Nkv) break;         // ragged last tile: a half-tile with no valid key is skipped (uniform)
             // ---- S^T = K . Q^T : 2 key tiles x QF query tiles
             f32x4_t s[2][QF];
 #pragma unroll
