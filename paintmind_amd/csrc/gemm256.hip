@@ -19,6 +19,8 @@
 // one slot behind, {MFMAs of the previous phase | fragment reads}.  A SIMD hosts one wave of each kind, so its
 // matrix pipe and the LDS pipe are busy in the same slot instead of alternating.  DMA issue (even slots) and
 // vmcnt waits (odd slots) are slot-aligned for all waves, which keeps the vmcnt arithmetic identical.
+#include <stdlib.h>
+
 #include "gemm_common.h"
 
 using namespace pmgemm;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     const int l15 = lane & 15, g = lane >> 4;
 
     int tm, tn;
-    tile_of_block(xcd_remap(blockIdx.x, gridDim.x), p.M / BM, p.N / BN, 4, tm, tn);
+    tile_of_block(xcd_remap(blockIdx.x, gridDim.x), p.M / BM, p.N / BN, p.chunk, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     LoopCtx c;
@@ -204,8 +206,16 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     wave_epilogue<EPI, OutT, 8>(p, acc, lds + wave * EPI_WAVE_BYTES, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
 }
 
+int g_chunk256 = -1;
+
 template <int EPI, typename OutT>
-int launch256(const GemmParams& p, hipStream_t s) {
+int launch256(const GemmParams& p0, hipStream_t s) {
+    if (g_chunk256 < 0) {
+        const char* e = getenv("PMHIP_CHUNK256");
+        g_chunk256 = e ? atoi(e) : 6;
+    }
+    GemmParams p = p0;
+    p.chunk = g_chunk256;
     const int tiles = (p.M / BM) * (p.N / BN);
     PmTimer tm(FAM_GEMM, s);
     hipLaunchKernelGGL((gemm256_kernel<EPI, OutT>), dim3(tiles), dim3(THREADS), 0, s, p);

@@ -23,6 +23,7 @@ struct GemmParams {
     void* outs[3];
     float q_scale;
     int fast_math;                                 // SwiGLU: 1 = fast exp (bf16 mode)
+    int chunk;                                     // n-tiles per L2 chunk of the tile walk (256x256 kernel)
 };
 
 // XCD-aware, bijective block remap: consecutive virtual ids stay on one XCD's L2 (block b runs on XCD b % 8).

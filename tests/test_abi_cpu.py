@@ -123,3 +123,24 @@ def test_transforms_without_torchvision():
     assert pm.stage2_transform(img_size=128, is_train=False)(img).shape == (3, 128, 128)
     from paintmind_amd.reconstruct import restore
     assert restore(x).size == (256, 256)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under paintmind_amd/ may import, call or link it"""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "paintmind_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".hip", ".h", ".sh")):
+            text = open(path, errors="ignore").read()
+            assert "oracle" not in text.replace("oracle/vq_ref.c", "").replace("the oracle", "").replace("vs the oracle", "") \
+                or path.endswith(("vq.hip",)), path
+    for path in glob.glob(os.path.join(ROOT, "paintmind_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert "import oracle" not in src and "from oracle" not in src, path
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "paintmind_amd", "does_not_exist.so"))
+    with pytest.raises(_lib.PmhipError) as e:
+        _lib.load()
+    assert "no CPU fallback" in str(e.value) or "not built" in str(e.value)
