@@ -256,6 +256,12 @@ def main():
         dist.gather(last, bufs, dst=0)
         return last
 
+    # one-time setup, not a benchmark step: the first two calls size the workspaces and capture the decode-loop
+    # graph of every lane (eager pass, capture pass); afterwards every call is a pure replay
+    log("setup (workspace sizing + hipGraph capture)")
+    for i in range(2):
+        step(-1 - i)
+    torch.cuda.synchronize(device)
     log("warm-up")
     for i in range(args.warmup):
         gather(step(i))
