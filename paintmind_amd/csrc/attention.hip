@@ -16,6 +16,10 @@
 // For bf16 the K rows of a tile are read in a permuted order so that the 8 keys a lane owns across
 // two S^T tiles are CONTIGUOUS, which makes the matching V^T operand one ds_read_b128.
 // V arrives pre-transposed ([B,H,64,Nkv_pad], written by the projection GEMM's epilogue).
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
     constexpr int TILE_BYTES = KT * C::ROWB;
     constexpr int STAGE_BYTES = 2 * TILE_BYTES;              // K tile + V^T tile
     constexpr float kDefer = EXP2 ? 8.0f : 0.0f;             // skip the O rescale while the row max grows < 2^8
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE_BYTES];   // 3-stage K / V^T ring
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -164,123 +168,178 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
     for (int j = 0; j < QF; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; }
 
     const int ntiles = (Nkv + KT - 1) / KT;
+    const int nhalves = (Nkv + 31) / 32;                     // 32-key half-tiles that contain at least one valid key
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    stage_tiles<T>(lds, Kbh, Vbh, v_row_bytes, 0, wave_u, lane);
+    constexpr int LOADS_PER_TILE = 2 * ((KT / (1024 / C::ROWB)) / 4);   // DMA instructions per wave per tile (K + V^T)
 
-    for (int t = 0; t < ntiles; ++t) {
-        unsigned char* Kl = lds + (t & 1) * STAGE_BYTES;
-        unsigned char* Vl = Kl + TILE_BYTES;
-        const int kv0 = t * KT;
-        // this wave's DMA of tile t has landed; after the barrier everybody's has, and every wave is done with
-        // the other stage (tile t-1), which the DMA of tile t+1 may now overwrite while tile t is multiplied
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < ntiles) stage_tiles<T>(lds + ((t + 1) & 1) * STAGE_BYTES, Kbh, Vbh, v_row_bytes, t + 1, wave_u, lane);
-        if (kv0 + KT > Nkv) {
-            zero_ragged_v<T>(Vl, kv0, Nkv, tid);
-            __syncthreads();
+    // S^T of one half-tile: 2 key tiles x QF query tiles
+    auto qk_half = [&](f32x4_t (&sd)[2][QF], int hh) {
+        const unsigned char* Kl = lds + ((hh >> 1) % 3) * STAGE_BYTES;
+        const int pc = hh & 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) sd[kk][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const int krow = key_of_row<T>(2 * pc + kk, l15);
+#pragma unroll
+            for (int c = 0; c < C::NCH; ++c) {
+                const uint4 kfrag = lds_chunk<T>(Kl, krow, c * 4 + g);
+#pragma unroll
+                for (int qf = 0; qf < QF; ++qf) Mma<T>::run(sd[kk][qf], kfrag, qreg[qf][c]);
+            }
         }
+    };
 
-        // The 64-key tile is consumed as two 32-key halves (S^T tiles 2*pc, 2*pc+1): half the S registers,
-        // and the softmax VALU of one half overlaps the MFMAs of the other across the co-resident waves.
+    // (1) row max of half-tile hh and the rare rescale branch
+    auto rowmax_rescale = [&](f32x4_t (&sc)[2][QF], int hh) {
+        const int t = hh >> 1, pc = hh & 1, kv0 = t * KT;
+        if (kv0 + KT > Nkv) {                                // ragged last tile: mask keys beyond Nkv
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc) {
-            if (kv0 + 32 * pc >= Nkv) break;         // ragged last tile: a half-tile with no valid key is skipped (uniform)
-            // ---- S^T = K . Q^T : 2 key tiles x QF query tiles
-            f32x4_t s[2][QF];
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kv0 + key_of_row<T>(2 * pc + kk, 4 * g + r);
+                    if (key >= Nkv) {
 #pragma unroll
-                for (int qf = 0; qf < QF; ++qf) s[kk][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                const int krow = key_of_row<T>(2 * pc + kk, l15);
-#pragma unroll
-                for (int c = 0; c < C::NCH; ++c) {
-                    const uint4 kfrag = lds_chunk<T>(Kl, krow, c * 4 + g);
-#pragma unroll
-                    for (int qf = 0; qf < QF; ++qf) Mma<T>::run(s[kk][qf], kfrag, qreg[qf][c]);
-                }
-            }
-            // mask keys beyond Nkv (only the last tile can be ragged)
-            if (kv0 + KT > Nkv) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kv0 + key_of_row<T>(2 * pc + kk, 4 * g + r);
-                        if (key >= Nkv) {
-#pragma unroll
-                            for (int qf = 0; qf < QF; ++qf) s[kk][qf][r] = -INFINITY;
-                        }
-                    }
-            }
-            // ---- online softmax per query column
-            float tmax[QF];
-            bool grow = false;
-#pragma unroll
-            for (int qf = 0; qf < QF; ++qf) {
-                float m = vmax3(s[0][qf][0], s[0][qf][1], s[0][qf][2]);
-                m = vmax3(m, s[0][qf][3], s[1][qf][0]);
-                m = vmax3(m, s[1][qf][1], s[1][qf][2]);
-                m = group4_max(vmax2(m, s[1][qf][3]));
-                tmax[qf] = m;
-                grow |= (m - mrun[qf] > kDefer);             // first half-tile: mrun = -inf -> true
-            }
-            if (__any(grow)) {                               // wave-uniform: rescale everything at the old max exactly once
-#pragma unroll
-                for (int qf = 0; qf < QF; ++qf) {
-                    // a half-tile of a ragged last tile may be fully masked (tmax = -inf): keep the max finite
-                    const float mnew = vmax3(mrun[qf], tmax[qf], -1e30f);
-                    const float alpha = EXP2 ? __builtin_amdgcn_exp2f(mrun[qf] - mnew) : expf(mrun[qf] - mnew);
-                    mrun[qf] = mnew;
-                    lrun[qf] *= alpha;
-#pragma unroll
-                    for (int df = 0; df < 4; ++df) {
-                        o[df][qf][0] *= alpha; o[df][qf][1] *= alpha; o[df][qf][2] *= alpha; o[df][qf][3] *= alpha;
+                        for (int qf = 0; qf < QF; ++qf) sc[kk][qf][r] = -INFINITY;
                     }
                 }
-            }
+        }
+        float tmax[QF];
+        bool grow = false;
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            float m = vmax3(sc[0][qf][0], sc[0][qf][1], sc[0][qf][2]);
+            m = vmax3(m, sc[0][qf][3], sc[1][qf][0]);
+            m = vmax3(m, sc[1][qf][1], sc[1][qf][2]);
+            m = group4_max(vmax2(m, sc[1][qf][3]));
+            tmax[qf] = m;
+            grow |= (m - mrun[qf] > kDefer);                 // first half-tile: mrun = -inf -> true
+        }
+        if (__any(grow)) {                                   // wave-uniform: rescale everything at the old max exactly once
 #pragma unroll
             for (int qf = 0; qf < QF; ++qf) {
-                const float m = mrun[qf];
-                float psum = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = EXP2 ? __builtin_amdgcn_exp2f(s[kk][qf][r] - m) : expf(s[kk][qf][r] - m);
-                        s[kk][qf][r] = pv;
-                        psum += pv;
-                    }
-                lrun[qf] += psum;
-            }
-            // ---- O^T += V^T . P^T
-            if constexpr (sizeof(T) == 2) {
-                uint4 pfrag[QF];
-#pragma unroll
-                for (int qf = 0; qf < QF; ++qf) pfrag[qf] = pack_p<bf16_t>(s[0][qf], s[1][qf]);
+                const float mnew = vmax3(mrun[qf], tmax[qf], -1e30f);
+                const float alpha = EXP2 ? __builtin_amdgcn_exp2f(mrun[qf] - mnew) : expf(mrun[qf] - mnew);
+                mrun[qf] = mnew;
+                lrun[qf] *= alpha;
 #pragma unroll
                 for (int df = 0; df < 4; ++df) {
-                    const uint4 vfrag = lds_chunk<T>(Vl, df * 16 + l15, pc * 4 + g);
-#pragma unroll
-                    for (int qf = 0; qf < QF; ++qf) Mma<T>::run(o[df][qf], vfrag, pfrag[qf]);
-                }
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    uint4 pfrag[QF];
-#pragma unroll
-                    for (int qf = 0; qf < QF; ++qf)
-                        pfrag[qf] = make_uint4(__float_as_uint(s[kk][qf][0]), __float_as_uint(s[kk][qf][1]),
-                                               __float_as_uint(s[kk][qf][2]), __float_as_uint(s[kk][qf][3]));
-#pragma unroll
-                    for (int df = 0; df < 4; ++df) {
-                        const uint4 vfrag = lds_chunk<T>(Vl, df * 16 + l15, (2 * pc + kk) * 4 + g);
-#pragma unroll
-                        for (int qf = 0; qf < QF; ++qf) Mma<T>::run(o[df][qf], vfrag, pfrag[qf]);
-                    }
+                    o[df][qf][0] *= alpha; o[df][qf][1] *= alpha; o[df][qf][2] *= alpha; o[df][qf][3] *= alpha;
                 }
             }
         }
+    };
+
+    // (2) ONE basic block: the exponentials / row sums / bf16 packing of half-tile hh (VALU + transcendental) and,
+    // when there is a next half-tile, the 16 MFMAs of its S^T -- independent work, interleaved by the scheduler
+    // directives below so the matrix pipe runs under the softmax instead of after it.
+    auto exp_and_next_qk = [&](auto has_next_c, f32x4_t (&sc)[2][QF], uint4 (&pfrag)[2][QF], f32x4_t (&sn)[2][QF], int hn) {
+        constexpr bool has_next = decltype(has_next_c)::value;      // compile-time: the steady-state region has no branch
+        if constexpr (has_next) qk_half(sn, hn);
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            const float m = mrun[qf];
+            float psum = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = EXP2 ? __builtin_amdgcn_exp2f(sc[kk][qf][r] - m) : expf(sc[kk][qf][r] - m);
+                    sc[kk][qf][r] = pv;
+                    psum += pv;
+                }
+            lrun[qf] += psum;
+            if constexpr (sizeof(T) == 2) {
+                pfrag[0][qf] = pack_p<bf16_t>(sc[0][qf], sc[1][qf]);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    pfrag[kk][qf] = make_uint4(__float_as_uint(sc[kk][qf][0]), __float_as_uint(sc[kk][qf][1]),
+                                               __float_as_uint(sc[kk][qf][2]), __float_as_uint(sc[kk][qf][3]));
+            }
+        }
+        if constexpr (sizeof(T) == 2 && EXP2 && has_next) {
+            {
+                // 4 K-fragment reads, then 16 x {1 MFMA, 5 VALU, 2 transcendental}
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                }
+            }
+        }
+    };
+
+    // (3) O^T += V^T . P^T for half-tile hh
+    auto pv_half = [&](uint4 (&pfrag)[2][QF], int hh) {
+        const int t = hh >> 1, pc = hh & 1;
+        const unsigned char* Vl = lds + (t % 3) * STAGE_BYTES + TILE_BYTES;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                const uint4 vfrag = lds_chunk<T>(Vl, df * 16 + l15, pc * 4 + g);
+#pragma unroll
+                for (int qf = 0; qf < QF; ++qf) Mma<T>::run(o[df][qf], vfrag, pfrag[0][qf]);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int df = 0; df < 4; ++df) {
+                    const uint4 vfrag = lds_chunk<T>(Vl, df * 16 + l15, (2 * pc + kk) * 4 + g);
+#pragma unroll
+                    for (int qf = 0; qf < QF; ++qf) Mma<T>::run(o[df][qf], vfrag, pfrag[kk][qf]);
+                }
+        }
+    };
+
+    // entering tile tn (called while the previous tile's second half is still to be consumed): its DMA has landed
+    // and is published by the barrier; the barrier also proves every wave is done with tile tn-2, whose stage the
+    // DMA of tile tn+1 now reuses (3-stage ring)
+    auto enter_tile = [&](int tn) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tn + 1 < ntiles) stage_tiles<T>(lds + ((tn + 1) % 3) * STAGE_BYTES, Kbh, Vbh, v_row_bytes, tn + 1, wave_u, lane);
+        if (tn * KT + KT > Nkv) {
+            zero_ragged_v<T>(lds + (tn % 3) * STAGE_BYTES + TILE_BYTES, tn * KT, Nkv, tid);
+            __syncthreads();
+        }
+    };
+
+    stage_tiles<T>(lds, Kbh, Vbh, v_row_bytes, 0, wave_u, lane);
+    (void)LOADS_PER_TILE;
+    enter_tile(0);
+
+    // Software pipeline over half-tiles: the MFMAs of S^T(h+1) are independent of the softmax VALU work on S^T(h),
+    // so the two interleave inside one wave; two named S buffers alternate (static register indexing).
+    f32x4_t sA[2][QF], sB[2][QF];
+    uint4 pfrag[2][QF];
+    constexpr std::true_type kNext{};
+    constexpr std::false_type kLast{};
+    qk_half(sA, 0);
+    int hs = 0;
+    for (; hs + 2 < nhalves; hs += 2) {                                  // steady state: both following halves exist
+        rowmax_rescale(sA, hs);
+        exp_and_next_qk(kNext, sA, pfrag, sB, hs + 1);                  // S^T(hs+1): same tile, second half
+        pv_half(pfrag, hs);
+        rowmax_rescale(sB, hs + 1);
+        enter_tile((hs + 2) >> 1);                                      // S^T(hs+2) opens the next tile
+        exp_and_next_qk(kNext, sB, pfrag, sA, hs + 2);
+        pv_half(pfrag, hs + 1);
+    }
+    rowmax_rescale(sA, hs);                                             // tail: one or two halves left
+    if (hs + 1 < nhalves) {
+        exp_and_next_qk(kNext, sA, pfrag, sB, hs + 1);
+        pv_half(pfrag, hs);
+        rowmax_rescale(sB, hs + 1);
+        exp_and_next_qk(kLast, sB, pfrag, sA, 0);
+        pv_half(pfrag, hs + 1);
+    } else {
+        exp_and_next_qk(kLast, sA, pfrag, sB, 0);
+        pv_half(pfrag, hs);
     }
 
     // ---- finalize: O = O^T / l, head-major inside the output row
