@@ -229,7 +229,13 @@ int pm_gemm256_supported(const GemmParams& p, int dtype, int epi, int out_dtype)
     if (dtype != PMHIP_BF16) return 0;
     if (p.M % BM || p.N % BN || p.K % KSTEP) return 0;
     if ((p.M / BM) * (p.N / BN) < 192) return 0;            // not enough tiles to fill 256 CUs: the small kernel wins
-    if (epi == EPI_STD && p.residual) return 0;             // the residual GEMMs keep the register-prefetch kernel
+    if (epi == EPI_STD && p.residual) {
+        // residual GEMMs: the 128x128 kernel prefetches the residual tile and overlaps two workgroups per CU, which wins
+        // while the GEMM is HBM-bound (small K); with a long K loop the faster main loop of this kernel wins
+        static int kmin = -1;
+        if (kmin < 0) { const char* e = getenv("PMHIP_G256_RES_KMIN"); kmin = e ? atoi(e) : 1024; }
+        if (p.K < kmin) return 0;
+    }
     (void)out_dtype;
     return 1;
 }

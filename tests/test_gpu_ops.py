@@ -45,6 +45,18 @@ def test_gemm_large_tile_kernel(M, N, K, out_dtype):
     assert blk.max() < (1e-3 if out_dtype == torch.float32 else 0.15 * np.abs(ref).max())
 
 
+def test_gemm_large_tile_kernel_with_residual():
+    """K >= 1024 residual GEMMs (the SwiGLU w3 shape) also take the 256x256 kernel; residual rows are tiled (res_rows)"""
+    M, N, K = 65536, 512, 1408
+    a, w, b = bf16_round(rnd(M, K)), bf16_round(rnd(N, K, scale=K ** -0.5)), rnd(N)
+    r = rnd(M, N)
+    out = n(ops.gemm(t(a, torch.bfloat16), t(w, torch.bfloat16), bias=t(b), residual=t(r), out_dtype=torch.float32))
+    assert rel_err(out, a @ w.T + b + r) < 2e-5
+    pos = rnd(1024, N)
+    out = n(ops.gemm(t(a, torch.bfloat16), t(w, torch.bfloat16), bias=t(b), residual=t(pos), res_rows=1024, out_dtype=torch.float32))
+    assert rel_err(out, a @ w.T + b + pos[np.arange(M) % 1024]) < 2e-5
+
+
 def test_swiglu_and_heads_large_tile_kernel():
     M, D, H = 16384, 512, 1368
     lin = torch.nn.Linear(D, 2 * H)
