@@ -228,7 +228,7 @@ int launch256(const GemmParams& p0, hipStream_t s) {
 int pm_gemm256_supported(const GemmParams& p, int dtype, int epi, int out_dtype) {
     if (dtype != PMHIP_BF16) return 0;
     if (p.M % BM || p.N % BN || p.K % KSTEP) return 0;
-    if ((p.M / BM) * (p.N / BN) < 192) return 0;            // not enough tiles to fill 256 CUs: the small kernel wins
+    if ((p.M / BM) * (p.N / BN) < 96) return 0;             // too few tiles: the small kernel has 4x the workgroups
     if (epi == EPI_STD && p.residual) {
         // residual GEMMs: the 128x128 kernel prefetches the residual tile and overlaps two workgroups per CU, which wins
         // while the GEMM is HBM-bound (small K); with a long K loop the faster main loop of this kernel wins
