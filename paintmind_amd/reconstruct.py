@@ -1,4 +1,5 @@
-"""Side-by-side reconstruction figure (reference paintmind/reconstruct.py:11-52)."""
+"""Side-by-side "origin | reconstruct" figure for a VQGAN checkpoint (what reference paintmind/reconstruct.py:23-52
+produces), built on this package's transform and model."""
 import io
 
 import numpy as np
@@ -8,38 +9,44 @@ from PIL import Image, ImageDraw, ImageFont
 from .factory import create_model
 from .utils.transform import stage1_transform
 
+_PANEL = 256
+
 
 def restore(x):
-    """[-1,1] CHW tensor -> PIL image (reconstruct.py:11-16)"""
-    x = (x + 1) * 0.5
-    x = x.permute(1, 2, 0).detach().cpu().numpy()
-    return Image.fromarray((255 * x).astype(np.uint8))
+    """CHW tensor in [-1, 1] -> 8-bit RGB PIL image (truncating, like the reference's astype(uint8))"""
+    arr = ((x.detach().float().cpu() + 1) * 0.5).permute(1, 2, 0).numpy()
+    return Image.fromarray((arr * 255).astype(np.uint8))
 
 
-def download_image(url):
-    import requests
-    resp = requests.get(url)
-    resp.raise_for_status()
-    return Image.open(io.BytesIO(resp.content))
+def _open(source):
+    if source.startswith("http"):
+        import requests
+        reply = requests.get(source)
+        reply.raise_for_status()
+        return Image.open(io.BytesIO(reply.content))
+    return Image.open(source).convert("RGB")
+
+
+def _label(figure, titles):
+    try:
+        font = ImageFont.truetype("arialbi.ttf", 16)
+    except Exception:
+        font = None
+    draw = ImageDraw.Draw(figure)
+    for column, title in enumerate(titles):
+        draw.text((column * _PANEL, 0), str(title), (255, 255, 255), font=font)
 
 
 def reconstruction(img_path=None, model_name='vit-s-vqgan', titles=['origin', 'reconstruct'], checkpoint_path=None, scale=0.8,
                    device='cuda', pretrained=True):
-    w, h = 256, 256
-    img = download_image(img_path) if img_path.startswith('http') else Image.open(img_path).convert('RGB')
-    img = stage1_transform(is_train=False, scale=scale)(img).to(device)
-    model = create_model(arch='vqgan', version=model_name, pretrained=pretrained, checkpoint_path=checkpoint_path).to(device)
-    model.eval()
+    """encode -> decode one image and return the two panels as a single PIL image"""
+    pixels = stage1_transform(is_train=False, scale=scale)(_open(img_path)).to(device)
+    model = create_model(arch='vqgan', version=model_name, pretrained=pretrained, checkpoint_path=checkpoint_path).to(device).eval()
     with torch.no_grad():
-        z, _, _ = model.encode(img.unsqueeze(0))
-        rec = model.decode(z).squeeze(0)
-    fig = Image.new("RGB", (2 * w, h))
-    fig.paste(restore(img), (0, 0))
-    fig.paste(restore(rec), (w, 0))
-    try:
-        font = ImageFont.truetype('arialbi.ttf', 16)
-    except Exception:
-        font = None
-    for i, title in enumerate(titles):
-        ImageDraw.Draw(fig).text((i * w, 0), f'{title}', (255, 255, 255), font=font)
-    return fig
+        latent = model.encode(pixels[None])[0]
+        rebuilt = model.decode(latent)[0]
+    figure = Image.new("RGB", (2 * _PANEL, _PANEL))
+    for column, panel in enumerate((pixels, rebuilt)):
+        figure.paste(restore(panel), (column * _PANEL, 0))
+    _label(figure, titles)
+    return figure
