@@ -122,6 +122,22 @@ int pmhip_vq_quantize(const float* z, const float* en, const float* sq, float be
                       int64_t* idx_out, float* loss_out, void* scratch, int M, int V, int E,
                       pmhip_stream stream);
 
+/* Per-sample random masking of the latent sequence (Pipeline.random_masking, generate.py:78-110):
+ * position i of sample b is KEPT iff fewer than len_keep positions of the sample have smaller noise
+ * (ties: smaller index first, i.e. the order of a stable ascending argsort); masked positions get
+ * mask_token.  z, x_out fp32 [B,N,E]; noise, mask_out fp32 [B,N] (mask: 0 keep, 1 masked);
+ * len_keep = N - max(int(N*mask_ratio),1) is computed by the caller (generate.py:86-87). */
+int pmhip_random_mask(const float* z, const float* noise, const float* mask_token, int len_keep,
+                      float* x_out, float* mask_out, int B, int N, int E, pmhip_stream stream);
+
+/* Masked label-smoothed cross entropy, forward only (Pipeline.loss, generate.py:112-125):
+ * row_loss[m] = mask[m] * CE(logits[m,:], labels[m]; label_smoothing) with torch's definition
+ * (1-eps)*nll + eps*mean_c(-log p_c); loss_out[0] = sum(row_loss) / sum(mask) (nan if nothing is
+ * masked, as in the reference).  logits fp32 [M,V] with row stride ldl, labels int64 in [0,V). */
+int pmhip_masked_ce(const float* logits, int ldl, const int64_t* labels, const float* mask,
+                    float label_smoothing, float* row_loss, float* loss_out, int M, int V,
+                    pmhip_stream stream);
+
 /* One MaskGIT sampling pass over logits rows (generate.py:163-173 with helpers :29-46):
  * top-k filter, gumbel-argmax at `temperature`, confidence from the UNfiltered softmax, merge into
  * the previously masked positions.  noise: NULL -> counter-based Philox keyed by

@@ -278,6 +278,43 @@ def sample_step(ids, mask_ratio, context, topk, temperature, noise, p, cfg, s2cf
 
 
 # ------------------------------------------------------------------------------------------------
+# masked-token objective, forward only (generate.py:78-146)
+# ------------------------------------------------------------------------------------------------
+def random_masking(x, mask_token, mask_ratio, noise):
+    """generate.py:78-110 given the uniforms of :89.  -> (x', mask) with mask 1 = replaced by mask_token"""
+    B, L, D = x.shape
+    len_keep = L - max(int(L * mask_ratio), 1)                                              # :86-87
+    order = np.argsort(noise, axis=1, kind="stable")                                        # :92 (ascending)
+    rank = np.argsort(order, axis=1, kind="stable")                                         # :93
+    mask = (rank >= len_keep).astype(F)                                                     # :103-107
+    out = np.where(mask[..., None] > 0, _f(mask_token).reshape(1, 1, D), _f(x))             # :95-101
+    return out.astype(F), mask
+
+
+def masked_ce(logits, labels, masks, label_smoothing=0.1):
+    """generate.py:112-125: F.cross_entropy(label_smoothing, reduction='none') * mask, / mask.sum()"""
+    x = logits.reshape(-1, logits.shape[-1]).astype(np.float64)
+    y = labels.reshape(-1)
+    m = masks.reshape(-1).astype(np.float64)
+    mx = x.max(1, keepdims=True)
+    logp = x - mx - np.log(np.exp(x - mx).sum(1, keepdims=True))
+    nll = -logp[np.arange(len(y)), y]
+    smooth = -logp.mean(1)
+    row = (1 - label_smoothing) * nll + label_smoothing * smooth
+    return F((row * m).sum() / m.sum()), (row * m).astype(F)
+
+
+def pipeline_forward(img, context, mask_ratio, noise, p, cfg, s2cfg):
+    """Pipeline.forward, generate.py:136-146 -> (loss, aux)"""
+    vq_p = {k[len("vqgan."):]: v for k, v in p.items() if k.startswith("vqgan.")}
+    z, _, idx = vqgan_encode(img, vq_p, cfg)
+    x, mask = random_masking(z, p["mask_token"], mask_ratio, noise)
+    logits = cond_transformer(x, context, p, s2cfg)
+    loss, row = masked_ce(logits, idx, mask)
+    return loss, {"x": x, "mask": mask, "logits": logits, "row_loss": row, "ids": idx}
+
+
+# ------------------------------------------------------------------------------------------------
 # Philox4x32-10, the counter-based generator of the perf-mode sampler (paintmind_amd/csrc/sample.hip)
 # ------------------------------------------------------------------------------------------------
 def philox4x32_10(c0, c1, c2, c3, k0, k1):

@@ -73,6 +73,8 @@ PROTOTYPES = {
     "pmhip_convert_pad": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "pmhip_add_rows": (i32, [vp, vp, i32, vp, i32, i32, vp]),
     "pmhip_embed_rows": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "pmhip_random_mask": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]),
+    "pmhip_masked_ce": (i32, [vp, i32, vp, vp, f32, vp, vp, i32, i32, vp]),
     "pmhip_vq_prepare": (i32, [vp, vp, vp, i32, i32, vp]),
     "pmhip_vq_scratch_bytes": (C.c_size_t, [i32, i32]),
     "pmhip_vq_quantize": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -99,9 +99,34 @@ class Pipeline(nn.Module):
     def from_pretrained(self, path):
         return self.load_state_dict(torch.load(path, map_location="cpu"))
 
-    # -- training-only members of the reference -----------------------------------------------------
-    def forward(self, img, text=None, mask_ratio=0.75):
-        raise NotImplementedError("paintmind_amd implements the generation path only (training forward/loss: out of scope)")
+    # -- masked-token objective, forward only (generate.py:78-146) ---------------------------------
+    # The HIP path has no backward: these return tensors without a grad_fn, for validation loss and
+    # for checking a training run's forward numerics.  Optimisation stays with the reference trainer.
+    @torch.no_grad()
+    def random_masking(self, x, mask_ratio, noise=None):
+        """(x [B,L,D], ratio) -> (x with masked positions replaced by mask_token, mask [B,L], 1 = masked)
+        (generate.py:78-110).  `noise` [B,L]: the uniforms the reference draws at :89 (default: torch.rand)."""
+        B, L, _ = x.shape
+        len_keep = L - max(int(L * mask_ratio), 1)
+        if noise is None:
+            noise = torch.rand(B, L, device=x.device)
+        return ops.random_mask(x.float().contiguous(), noise.float().contiguous(),
+                               self.mask_token.data.float().reshape(-1).contiguous(), len_keep)
+
+    @torch.no_grad()
+    def loss(self, logit, label, masks):
+        """label-smoothed (0.1) cross entropy averaged over the masked positions (generate.py:112-125)"""
+        V = logit.shape[-1]
+        out, _ = ops.masked_ce(logit.float().reshape(-1, V).contiguous(), label.reshape(-1).contiguous(),
+                               masks.float().reshape(-1).contiguous(), 0.1)
+        return out.reshape(())
+
+    @torch.no_grad()
+    def forward(self, img, text=None, mask_ratio=0.75, noise=None):
+        """generate.py:136-146: encode -> random masking -> stage-2 logits -> masked cross entropy"""
+        x, ids, text = self.to_latent(img, text)
+        x, mask = self.random_masking(x, mask_ratio, noise)
+        return self.loss(self.tokens2logits(x, text), ids, mask)
 
     # -- inference API ------------------------------------------------------------------------------
     @torch.no_grad()

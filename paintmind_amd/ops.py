@@ -236,6 +236,32 @@ def remask(ids, scores, num_mask, mask_id):
     return ids
 
 
+def random_mask(z, noise, mask_token, len_keep):
+    """z fp32 [B,N,E], noise fp32 [B,N], mask_token fp32 [E] -> (x [B,N,E], mask [B,N] with 1 = masked)."""
+    dev = _dev(z, noise, mask_token)
+    lib = _lib.load()
+    B, N, E = z.shape
+    x = torch.empty_like(z)
+    mask = torch.empty(B, N, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_random_mask(_p(z), _p(noise), _p(mask_token), int(len_keep), _p(x), _p(mask), B, N, E,
+                                    stream_ptr(dev)), "pmhip_random_mask")
+    return x, mask
+
+
+def masked_ce(logits, labels, mask, label_smoothing=0.1):
+    """logits fp32 [M,V], labels int64 [M], mask fp32 [M] -> (loss [1], row_loss [M])."""
+    dev = _dev(logits, labels, mask)
+    lib = _lib.load()
+    M, V = logits.shape
+    row_loss = torch.empty(M, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_masked_ce(_p(logits), logits.stride(0), _p(labels), _p(mask), float(label_smoothing), _p(row_loss),
+                                  _p(loss), M, V, stream_ptr(dev)), "pmhip_masked_ce")
+    return loss, row_loss
+
+
 # ------------------------------------------------------------------------------------------------
 def timing_enable(on=True):
     check(_lib.load().pmhip_timing_enable(int(on)))

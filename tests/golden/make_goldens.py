@@ -2,7 +2,7 @@
 development container only -- see _ref_import.py).  The fixtures are data: seeded inputs and the
 reference's outputs.  Run:  python tests/golden/make_goldens.py
 
-F1  tiny_vqgan.npz / tiny_pipeline.npz : tiny configs, weights + inputs + intermediates
+F1  tiny_vqgan.npz / tiny_pipeline.npz / tiny_forward.npz : tiny configs, weights + inputs + intermediates
 F2  full_vqgan.npz / full_stage2.npz   : full-size configs; weights are NOT stored -- both sides
     re-create them with torch.manual_seed(seed) + create_model (bit-identical init, checked by sha256)
 F3  api.json                            : API-behaviour facts (shapes, dtypes, list lengths, errors)
@@ -116,7 +116,7 @@ def tiny_vqgan():
     return m
 
 
-def tiny_pipeline():
+def _build_tiny_pipe():
     ref_cfg["tiny-vqgan"] = my_cfg["tiny-vqgan"]
     cfg = {k: v for k, v in my_cfg["tiny-pipeline"].items() if k not in ("text_model", "context_dim")}
     ctx_dim = my_cfg["tiny-pipeline"]["context_dim"]
@@ -147,6 +147,11 @@ def tiny_pipeline():
             v.copy_(torch.randn(v.shape, generator=g) * 0.05)
         elif "norm" in k and k.endswith("weight"):
             v.copy_(1 + torch.randn(v.shape, generator=g) * 0.1)
+    return pipe, ctx_dim
+
+
+def tiny_pipeline():
+    pipe, ctx_dim = _build_tiny_pipe()
     out = {"w:" + k: v for k, v in sd_np(pipe).items()}
     B, N, V = 3, pipe.num_tokens, 64
     ctx = torch.randn(B, 77, ctx_dim, generator=torch.Generator().manual_seed(23))
@@ -211,6 +216,51 @@ def tiny_pipeline():
     return api
 
 
+def tiny_forward():
+    """Pipeline.forward / random_masking / loss (generate.py:78-146) on the tiny pipeline of tiny_pipeline.npz."""
+    pipe, ctx_dim = _build_tiny_pipe()
+    out = {"weights_sha": np.frombuffer(bytes.fromhex(sd_sha(pipe)), dtype=np.uint8)}
+    B, N, V = 3, pipe.num_tokens, 64
+    img = torch.rand(B, 3, 32, 32, generator=torch.Generator().manual_seed(51)) * 2 - 1
+    ctx = torch.randn(B, 77, ctx_dim, generator=torch.Generator().manual_seed(52))
+    out["img"], out["context"] = img.numpy(), ctx.numpy()
+    # random_masking alone: the noise is the first draw after manual_seed (generate.py:89)
+    x = torch.randn(B, N, pipe.mask_token.shape[1], generator=torch.Generator().manual_seed(53))
+    out["rm_x"] = x.numpy()
+    for i, ratio in enumerate((0.75, 0.3, 0.01, 1.0)):
+        torch.manual_seed(60 + i)
+        noise = torch.rand(B, N)
+        torch.manual_seed(60 + i)
+        xm, mask = pipe.random_masking(x, ratio)
+        assert noise.flatten().unique().numel() == B * N          # no ties: the sort order is well defined
+        out[f"rm{i}_ratio"], out[f"rm{i}_noise"], out[f"rm{i}_x"], out[f"rm{i}_mask"] = (
+            np.float64(ratio), noise.numpy(), xm.numpy(), mask.numpy())
+    # loss alone
+    logit = torch.randn(B, N, V, generator=torch.Generator().manual_seed(54)) * 3
+    label = torch.randint(0, V, (B, N), generator=torch.Generator().manual_seed(55))
+    masks = (torch.rand(B, N, generator=torch.Generator().manual_seed(56)) < 0.6).float()
+    out["ce_logit"], out["ce_label"], out["ce_mask"] = logit.numpy(), label.numpy(), masks.numpy()
+    out["ce_loss"] = pipe.loss(logit, label, masks).numpy()
+    out["ce_rows"] = torch.nn.functional.cross_entropy(logit.view(-1, V), label.view(-1), label_smoothing=0.1,
+                                                       reduction="none").numpy()
+    # whole forward, with and without text
+    for tag, text in (("ctx", ctx), ("noctx", None)):
+        real_text_model = pipe.text_model
+        pipe.text_model = torch.nn.Identity()                      # feed the context tensor straight through
+        try:
+            for j, ratio in enumerate((0.75, 0.4)):
+                torch.manual_seed(70 + j)
+                noise = torch.rand(B, N)
+                torch.manual_seed(70 + j)
+                loss = pipe(img, text, mask_ratio=ratio)
+                out[f"fw_{tag}{j}_ratio"], out[f"fw_{tag}{j}_noise"], out[f"fw_{tag}{j}_loss"] = (
+                    np.float64(ratio), noise.numpy(), loss.numpy())
+        finally:
+            pipe.text_model = real_text_model
+    save("tiny_forward.npz", **out)
+    return {}
+
+
 def full_vqgan():
     torch.manual_seed(0)
     m = ref.create_model(arch="vqgan", version="vit-s-vqgan", pretrained=False).eval()
@@ -264,7 +314,7 @@ def full_stage2():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny_vqgan", "tiny_pipeline", "full_vqgan", "full_stage2"]
+    which = sys.argv[1:] or ["tiny_vqgan", "tiny_pipeline", "tiny_forward", "full_vqgan", "full_stage2"]
     api_path = os.path.join(HERE, "api.json")
     api = json.load(open(api_path)) if os.path.exists(api_path) else {}
     api["torch_version"] = torch.__version__
@@ -272,6 +322,8 @@ if __name__ == "__main__":
         tiny_vqgan()
     if "tiny_pipeline" in which:
         api.update(tiny_pipeline())
+    if "tiny_forward" in which:
+        api.update(tiny_forward())
     if "full_vqgan" in which:
         api.update(full_vqgan())
     if "full_stage2" in which:

@@ -322,3 +322,25 @@ def test_large_text_configs_against_oracle(name, B):
     img_ref = O.vqgan_decode_indices(pred_ref[:1], vq_p, vcfg)
     img_gpu = pipe.vqgan.decode_from_indice(torch.from_numpy(pred_ref[:1]).to(dev()))
     assert maxabs(n(img_gpu), img_ref) < TOL
+
+
+# ---- masked-token objective, forward only (generate.py:78-146) ---------------------------------------
+def test_tiny_pipeline_forward_loss_golden(tiny_pipe):
+    pipe, p, _ = tiny_pipe
+    tf = load_golden("tiny_forward.npz")[1]
+    for i in range(4):
+        x, mask = pipe.random_masking(t(tf["rm_x"]), float(tf[f"rm{i}_ratio"]), noise=t(tf[f"rm{i}_noise"]))
+        assert np.array_equal(n(mask), tf[f"rm{i}_mask"]) and np.array_equal(n(x), tf[f"rm{i}_x"])
+    loss = pipe.loss(t(tf["ce_logit"]), t(tf["ce_label"]), t(tf["ce_mask"]))
+    assert loss.shape == () and abs(float(loss) - float(tf["ce_loss"])) < 1e-4
+    text_model = pipe.text_model
+    pipe.text_model = torch.nn.Identity()
+    try:
+        for tag, ctx in (("ctx", t(tf["context"])), ("noctx", None)):
+            for j in range(2):
+                loss = pipe(t(tf["img"]), ctx, mask_ratio=float(tf[f"fw_{tag}{j}_ratio"]), noise=t(tf[f"fw_{tag}{j}_noise"]))
+                assert abs(float(loss) - float(tf[f"fw_{tag}{j}_loss"])) < TOL
+        # default noise path: torch.rand on the device, loss of an untrained model is about log(V)
+        assert 0.5 * np.log(64) < float(pipe(t(tf["img"]), None)) < 2 * np.log(64)
+    finally:
+        pipe.text_model = text_model

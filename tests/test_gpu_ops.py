@@ -9,6 +9,8 @@ from gpu_common import bf16_round, dev, n, rel_err, t
 from oracle import paintmind_oracle as O
 from oracle import vq_ref
 from paintmind_amd import ops, packing
+from paintmind_amd._lib import PmhipError
+from util import maxabs
 
 pytestmark = pytest.mark.gpu
 RNG = np.random.default_rng(1234)
@@ -243,3 +245,43 @@ def test_remask_exact_with_ties(B, N, m):
     out = n(ops.remask(t(ids), t(scores), m, 8192))
     assert np.array_equal(out, ref)
     assert np.all((out == 8192).sum(1) == m)
+
+
+# ---- masked-token objective kernels (loss.hip) -------------------------------------------------------
+@pytest.mark.parametrize("B,N,E,ratio", [(2, 16, 8, 0.75), (3, 1024, 32, 0.55), (1, 1500, 32, 0.999), (2, 64, 4, 0.0)])
+def test_random_mask_matches_oracle_with_ties(B, N, E, ratio):
+    rng = np.random.default_rng(B * N + E)
+    z = rng.standard_normal((B, N, E)).astype(np.float32)
+    noise = (rng.integers(0, max(N // 3, 2), (B, N)) / N).astype(np.float32)      # many ties: stable order decides
+    tok = rng.standard_normal(E).astype(np.float32)
+    len_keep = N - max(int(N * ratio), 1)
+    x, mask = ops.random_mask(t(z), t(noise), t(tok), len_keep)
+    xo, mo = O.random_masking(z, tok, ratio, noise)
+    assert np.array_equal(n(mask), mo) and np.array_equal(n(x), xo)
+    assert n(mask).sum(1).tolist() == [N - len_keep] * B
+
+
+@pytest.mark.parametrize("M,V,eps", [(48, 64, 0.1), (300, 1000, 0.0), (4096, 8192, 0.1), (17, 8200, 0.3)])
+def test_masked_ce_matches_oracle(M, V, eps):
+    rng = np.random.default_rng(M + V)
+    logits = (rng.standard_normal((M, V)) * 4).astype(np.float32)
+    labels = rng.integers(0, V, M)
+    mask = (rng.random(M) < 0.5).astype(np.float32)
+    loss, rows = ops.masked_ce(t(logits), t(labels), t(mask), eps)
+    lo, ro = O.masked_ce(logits, labels, mask, eps)
+    assert maxabs(n(rows), ro) < 1e-4
+    assert abs(float(loss) - float(lo)) < 1e-4
+    ref = torch.nn.functional.cross_entropy(torch.from_numpy(logits), torch.from_numpy(labels), label_smoothing=eps,
+                                            reduction="none").numpy()
+    assert maxabs(n(rows), ref * mask) < 1e-4
+
+
+def test_masked_ce_nothing_masked_is_nan_and_bad_args_raise():
+    logits = torch.zeros(8, 64, device=dev())
+    labels = torch.zeros(8, dtype=torch.int64, device=dev())
+    loss, _ = ops.masked_ce(logits, labels, torch.zeros(8, device=dev()), 0.1)
+    assert np.isnan(float(loss))
+    with pytest.raises(PmhipError):
+        ops.masked_ce(logits, labels, torch.zeros(8, device=dev()), 1.5)
+    with pytest.raises(PmhipError):
+        ops.random_mask(torch.zeros(1, 8, 4, device=dev()), torch.zeros(1, 8, device=dev()), torch.zeros(4, device=dev()), 9)

@@ -159,3 +159,34 @@ def test_torch_port_matches_goldens(tv, tp):
                                           torch.from_numpy(d2["s5_ctx_noise"]), pt2, cfg, s2_cfg("tiny-pipeline"))
         assert maxabs(logits.numpy(), d2["logits_ctx"]) < 5e-5
         assert np.array_equal(ids.numpy(), d2["s5_ctx_ids"]) and maxabs(img.numpy(), d2["s5_ctx_img"]) < 5e-5
+
+
+# ---- masked-token objective, forward only (generate.py:78-146) ---------------------------------------
+@pytest.fixture(scope="module")
+def tf():
+    return load_golden("tiny_forward.npz")[1]
+
+
+def test_random_masking_golden(tp, tf):
+    p, _ = tp
+    for i in range(4):
+        x, mask = O.random_masking(tf["rm_x"], p["mask_token"], float(tf[f"rm{i}_ratio"]), tf[f"rm{i}_noise"])
+        assert np.array_equal(mask, tf[f"rm{i}_mask"])
+        assert np.array_equal(x, tf[f"rm{i}_x"])
+    assert tf["rm2_mask"].sum(1).tolist() == [1, 1, 1]            # ratio 0.01 -> max(int(L*r),1) = 1 masked
+    assert tf["rm3_mask"].min() == 1                              # ratio 1.0 -> everything masked
+
+
+def test_masked_cross_entropy_golden(tf):
+    loss, rows = O.masked_ce(tf["ce_logit"], tf["ce_label"], tf["ce_mask"], 0.1)
+    assert abs(float(loss) - float(tf["ce_loss"])) < 1e-5
+    assert maxabs(rows, tf["ce_rows"] * tf["ce_mask"].reshape(-1)) < 1e-5
+
+
+def test_pipeline_forward_loss_golden(tp, tf):
+    p, _ = tp
+    cfg, s2 = vq_cfg("tiny-vqgan"), s2_cfg("tiny-pipeline")
+    for tag, ctx in (("ctx", tf["context"]), ("noctx", None)):
+        for j in range(2):
+            loss, _ = O.pipeline_forward(tf["img"], ctx, float(tf[f"fw_{tag}{j}_ratio"]), tf[f"fw_{tag}{j}_noise"], p, cfg, s2)
+            assert abs(float(loss) - float(tf[f"fw_{tag}{j}_loss"])) < 2e-5
