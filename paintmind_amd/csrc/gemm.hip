@@ -21,6 +21,9 @@ using namespace pmgemm;
 // gemm256.hip
 int pm_gemm256_supported(const GemmParams& p, int dtype, int epi, int out_dtype);
 int pm_gemm256_launch(const GemmParams& p, int epi, int out_dtype, hipStream_t s);
+// gemm2b.hip
+int pm_gemm2b_supported(const GemmParams& p, int dtype, int epi, int out_dtype);
+int pm_gemm2b_launch(const GemmParams& p, int epi, int out_dtype, hipStream_t s);
 
 namespace {
 
@@ -145,6 +148,21 @@ bool use256(const GemmParams& p, int dtype, int epi, int out_dtype) {
     return g_use256 && pm_gemm256_supported(p, dtype, epi, out_dtype);
 }
 
+int g_use2b = -1;       // PMHIP_GEMM2B: 0 = never, 1 = where it wins (default), 2 = wherever it is supported (development)
+
+// The two-workgroups-per-CU kernel (gemm2b.hip) takes the residual GEMMs with a short K loop (attention out-proj,
+// K = inner): they are HBM-bound (fp32 residual in, fp32 out) and it streams them at ~4.5 TB/s where the 128x128
+// kernel reaches 3.6.  Everything else measured equal or slower than gemm256.hip (tools/gemm_bench.py).
+bool use2b(const GemmParams& p, int dtype, int epi, int out_dtype) {
+    if (g_use2b < 0) {
+        const char* e = getenv("PMHIP_GEMM2B");
+        g_use2b = e ? atoi(e) : 1;
+    }
+    if (!g_use2b || !pm_gemm2b_supported(p, dtype, epi, out_dtype)) return false;
+    if (g_use2b >= 2) return true;
+    return epi == EPI_STD && p.residual && !pm_gemm256_supported(p, dtype, epi, out_dtype);
+}
+
 int check_common(const GemmParams& p, int dtype) {
     PM_REQUIRE(dtype == PMHIP_F32 || dtype == PMHIP_BF16, "gemm: bad dtype %d", dtype);
     PM_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
@@ -171,6 +189,7 @@ extern "C" int pmhip_gemm(int dtype, const void* A, int lda, const void* W, int 
     PM_REQUIRE(out_dtype == PMHIP_F32 || out_dtype == dtype, "gemm: out dtype must be f32 or the compute dtype");
     PM_REQUIRE(out_dtype == PMHIP_F32 || ldo % 8 == 0, "gemm: bf16 output needs ldo to be a multiple of 8");
     hipStream_t s = (hipStream_t)stream;
+    if (use2b(p, dtype, EPI_STD, out_dtype)) return pm_gemm2b_launch(p, EPI_STD, out_dtype, s);
     if (use256(p, dtype, EPI_STD, out_dtype)) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_STD, float>(p, s);
     if (out_dtype == PMHIP_F32) return launch<bf16_t, EPI_STD, float>(p, s);
@@ -187,6 +206,7 @@ extern "C" int pmhip_gemm_swiglu(int dtype, const void* A, int lda, const void* 
     PM_REQUIRE(Hp % 64 == 0, "gemm_swiglu: padded hidden width %d must be a multiple of 64", Hp);
     PM_REQUIRE(b12p && out && ldo % 8 == 0, "gemm_swiglu: bias/out required, ldo multiple of 8");
     hipStream_t s = (hipStream_t)stream;
+    if (use2b(p, dtype, EPI_SWIGLU, dtype)) return pm_gemm2b_launch(p, EPI_SWIGLU, dtype, s);
     if (use256(p, dtype, EPI_SWIGLU, dtype)) return pm_gemm256_launch(p, EPI_SWIGLU, dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_SWIGLU, float>(p, s);
     return launch<bf16_t, EPI_SWIGLU, bf16_t>(p, s);
@@ -211,6 +231,7 @@ extern "C" int pmhip_gemm_heads(int dtype, const void* A, int lda, const void* W
     }
     PM_TRY(check_common(p, dtype));
     hipStream_t s = (hipStream_t)stream;
+    if (use2b(p, dtype, EPI_HEADS, dtype)) return pm_gemm2b_launch(p, EPI_HEADS, dtype, s);
     if (use256(p, dtype, EPI_HEADS, dtype)) return pm_gemm256_launch(p, EPI_HEADS, dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_HEADS, float>(p, s);
     return launch<bf16_t, EPI_HEADS, bf16_t>(p, s);

@@ -203,7 +203,13 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
 
     // every fragment read finished before the last barrier: the whole LDS is free for the epilogue
     const float4 no_pre[1] = {};
-    wave_epilogue<EPI, OutT, 8>(p, acc, lds + wave * EPI_WAVE_BYTES, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
+    unsigned char* eraw = lds + wave * EPI_WAVE_BYTES;
+    if constexpr (EPI == EPI_STD && sizeof(OutT) == 4) {
+        if (p.residual) wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
+        else wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
+    } else {
+        wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
+    }
 }
 
 int g_chunk256 = -1;

@@ -62,9 +62,12 @@ __device__ __forceinline__ float silu_mul(float x1, float x2, int fast) {
 // operand: a lane owns row l15 of a 16-row group and 4 consecutive columns per 16x16 tile).  The tile is
 // transposed 16 rows at a time through `eraw` (>= EPI_WAVE_BYTES of LDS nobody else touches) so that every
 // global access covers 128-256 contiguous bytes per row.  `rpre` (used when NPRE > 1) holds the residual tile
-// prefetched in the store layout: element [mi*ITERS + it].
+// prefetched in the store layout: element [mi*ITERS + it].  FULL: the tile is known to lie inside the matrix (no
+// predicates, so the slices are straight-line code and the compiler can count its vmcnt waits instead of draining
+// the store queue at every branch join).  RES: 1 / 0 = residual known present / absent at compile time (-1: runtime);
+// with FULL && RES == 1 the residual rows of slice mi+1 are requested before slice mi's stores are issued.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, typename OutT, int MI, int NPRE>
+template <int EPI, typename OutT, int MI, int NPRE, bool FULL = false, int RES = -1>
 __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][4], unsigned char* eraw, int mwave,
                                               int nw, int lane, const float4 (&rpre)[NPRE]) {
     constexpr int CPL = 16 / (int)sizeof(OutT);                    // columns per lane per store (16 B)
@@ -72,7 +75,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
     const int l15 = lane & 15, g = lane >> 4;
     const int ccol = (lane % LPR) * CPL, ncol = nw + ccol;
     float* ebuf = reinterpret_cast<float*>(eraw);
-    if (nw >= p.N) return;
+    if (!FULL && nw >= p.N) return;
 
     if constexpr (EPI == EPI_HEADS) {
         // V part: 64-token x 64-d blocks are transposed through LDS as OutT so that V^T[b,h,d,:] rows are written
@@ -84,7 +87,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             for (int blk = 0; blk < MI / 4; ++blk) {
                 const int mblk = mwave + blk * 64;
                 const int b0 = mblk / p.tokens, t0 = mblk % p.tokens;
-                const bool whole = (mblk + 63 < p.M) && (t0 + 63 < p.tokens) && (t0 % 8 == 0);
+                const bool whole = (FULL || mblk + 63 < p.M) && (t0 + 63 < p.tokens) && (t0 % 8 == 0);
                 if (whole && sizeof(OutT) == 2) {
                     OutT* vbuf = reinterpret_cast<OutT*>(eraw);                  // [64 d][64 tokens]
 #pragma unroll
@@ -128,7 +131,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
 #pragma unroll
     for (int j = 0; j < CPL; ++j) bias_v[j] = 0.f;
     if constexpr (EPI == EPI_STD) {
-        if (p.bias && ncol < p.N) {
+        if (p.bias && (FULL || ncol < p.N)) {
 #pragma unroll
             for (int j = 0; j < CPL; j += 4) {
                 const float4 bb = *reinterpret_cast<const float4*>(p.bias + ncol + j);
@@ -136,8 +139,38 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             }
         }
     }
+    float4 sb[4] = {};                                             // SwiGLU: this lane's bias slices (x1 | x2, 8 each)
+    if constexpr (EPI == EPI_SWIGLU) {
+        const int q = lane & 3;
+        const float* b1 = p.bias + nw + (q >> 1) * 32 + (q & 1) * 8;
+        sb[0] = *reinterpret_cast<const float4*>(b1);      sb[1] = *reinterpret_cast<const float4*>(b1 + 4);
+        sb[2] = *reinterpret_cast<const float4*>(b1 + 16); sb[3] = *reinterpret_cast<const float4*>(b1 + 20);
+    }
+    // Retire the bias loads HERE, on every path, with a wait the compiler can see.  Otherwise each predicated
+    // store block below gets its own `s_waitcnt vmcnt(0)` for the bias registers (the skipped-path state never
+    // clears), and because vmcnt counts stores too, every 16-row slice then waits for the previous slice's stores
+    // to be acknowledged by L2 instead of streaming them.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0); expcnt / lgkmcnt untouched
+    constexpr bool PIPE_RES = (EPI == EPI_STD) && FULL && RES == 1 && NPRE == 1 && sizeof(OutT) == 4;
+    float4 rnext[ITERS] = {};
+    if constexpr (PIPE_RES) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+            rnext[it] = *reinterpret_cast<const float4*>(p.residual + (size_t)((mwave + it * RPI + lane / LPR) % p.res_rows) * p.ldr + ncol);
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+        float4 rcur[ITERS];
+        if constexpr (PIPE_RES) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) rcur[it] = rnext[it];
+            if (mi + 1 < MI) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it)
+                    rnext[it] = *reinterpret_cast<const float4*>(
+                        p.residual + (size_t)((mwave + (mi + 1) * 16 + it * RPI + lane / LPR) % p.res_rows) * p.ldr + ncol);
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
             *reinterpret_cast<f32x4_t*>(ebuf + l15 * ESTRIDE + ni * 16 + g * 4) = acc[mi][ni];
@@ -150,17 +183,18 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             for (int it = 0; it < ITERS; ++it) {
                 const int r = it * RPI + lane / LPR;
                 const int mm = mbase + r;
-                if (mm < p.M && ncol < p.N) {
+                if (FULL || (mm < p.M && ncol < p.N)) {
                     float v[CPL];
 #pragma unroll
                     for (int j = 0; j < CPL; j += 4) {
                         const float4 t = *reinterpret_cast<const float4*>(ebuf + r * ESTRIDE + ccol + j);
                         v[j] = t.x + bias_v[j]; v[j + 1] = t.y + bias_v[j + 1]; v[j + 2] = t.z + bias_v[j + 2]; v[j + 3] = t.w + bias_v[j + 3];
                     }
-                    if constexpr (sizeof(OutT) == 4) {
-                        if (p.residual) {
+                    if constexpr (sizeof(OutT) == 4 && RES != 0) {
+                        if (RES == 1 || p.residual) {
                             float4 rr;
-                            if constexpr (NPRE > 1) rr = rpre[mi * ITERS + it];      // compile-time index: stays in registers
+                            if constexpr (PIPE_RES) rr = rcur[it];
+                            else if constexpr (NPRE > 1) rr = rpre[mi * ITERS + it]; // compile-time index: stays in registers
                             else rr = *reinterpret_cast<const float4*>(p.residual + (size_t)(mm % p.res_rows) * p.ldr + ncol);
                             v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                         }
@@ -172,15 +206,13 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             // wave columns: [x1 0-15 | x2 0-15 | x1 16-31 | x2 16-31] of 32 hidden columns; lane (erow, q) gates
             // hidden columns q*8 .. q*8+7
             const int erow = lane >> 2, m = mbase + erow;
-            if (m < p.M) {
+            if (FULL || m < p.M) {
                 const int q = lane & 3;
                 const int c1 = (q >> 1) * 32 + (q & 1) * 8;          // x1 column inside the wave tile
                 const float* e1 = ebuf + erow * ESTRIDE + c1;
                 const float4 a0 = *reinterpret_cast<const float4*>(e1), a1 = *reinterpret_cast<const float4*>(e1 + 4);
                 const float4 g0 = *reinterpret_cast<const float4*>(e1 + 16), g1 = *reinterpret_cast<const float4*>(e1 + 20);
-                const float* b1 = p.bias + nw + c1;
-                const float4 ba0 = *reinterpret_cast<const float4*>(b1), ba1 = *reinterpret_cast<const float4*>(b1 + 4);
-                const float4 bg0 = *reinterpret_cast<const float4*>(b1 + 16), bg1 = *reinterpret_cast<const float4*>(b1 + 20);
+                const float4 ba0 = sb[0], ba1 = sb[1], bg0 = sb[2], bg1 = sb[3];
                 float h[8];
                 h[0] = silu_mul(a0.x + ba0.x, g0.x + bg0.x, p.fast_math); h[1] = silu_mul(a0.y + ba0.y, g0.y + bg0.y, p.fast_math);
                 h[2] = silu_mul(a0.z + ba0.z, g0.z + bg0.z, p.fast_math); h[3] = silu_mul(a0.w + ba0.w, g0.w + bg0.w, p.fast_math);
@@ -205,7 +237,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             for (int it = 0; it < ITERS; ++it) {
                 const int r = it * RPI + lane / LPR;
                 const int mm = mbase + r;
-                if (mm < p.M) {
+                if (FULL || mm < p.M) {
                     const int b = mm / p.tokens, t = mm % p.tokens;
                     float v[CPL];
 #pragma unroll
