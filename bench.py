@@ -322,7 +322,7 @@ def main():
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         ach = gf / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
         result["roofline"] = {
-            "kernel": "GEMM family (gemm256_kernel + gemm_nt_kernel, all launches of one step)", "bound": "mfma",
+            "kernel": "GEMM family (gemm256_kernel + gemm2b_kernel + gemm_nt_kernel, all launches of one step)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(args.workload, args.dtype), "launches": n_g,
             "avg_launch_ms": round(ms_g / max(n_g, 1), 4), "algorithmic_gflop_per_launch": round(gf / max(n_g, 1) / 1e9, 2)}

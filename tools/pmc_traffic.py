@@ -13,7 +13,7 @@ import sys
 
 
 def family(name):
-    if "gemm256" in name or "gemm_nt" in name:
+    if "gemm256" in name or "gemm_nt" in name or "gemm2b" in name:
         return "gemm"
     if "attention" in name:
         return "attention"

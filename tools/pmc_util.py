@@ -13,7 +13,7 @@ import sys
 
 def short(name):
     for key, tag in (("gemm256_kernel<0", "gemm256 plain (logits)"), ("gemm256_kernel<1", "gemm256 SwiGLU"),
-                     ("gemm256_kernel<2", "gemm256 head-split QKV"), ("gemm_nt_kernel", "gemm128 (residual / small)"),
+                     ("gemm256_kernel<2", "gemm256 head-split QKV"), ("gemm2b_kernel", "gemm2b (short-K residual)"), ("gemm_nt_kernel", "gemm128 (small)"),
                      ("attention_kernel", "attention"), ("layernorm", "layernorm"), ("sample_rows", "sample_rows")):
         if key in name:
             return tag
