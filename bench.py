@@ -235,6 +235,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs a {args.gpus}-rank launch (torch.distributed.run), WORLD_SIZE={world}")
+    if rank != 0:
+        # only rank 0 reports; the other ranks' stdout would only carry library banners (RCCL prints its version
+        # there) that could land after rank 0's JSON line
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = None
@@ -249,12 +253,27 @@ def main():
     step = make_step(args.workload, model, device, rank, decode_every_step=not args.final_decode_only)
     B = WORKLOADS[args.workload][1]
 
-    def gather(last):
+    recv = {}                                    # rank 0: receive buffers per (lane, shape), allocated once
+
+    def gather(last, lane=0):
+        """the path's only collective: finished images -> rank 0 (RCCL gather on the calling stream)"""
         if dist is None:
             return last
-        bufs = [torch.empty_like(last) for _ in range(world)] if rank == 0 else None
+        bufs = None
+        if rank == 0:
+            key = (lane, tuple(last.shape))
+            if key not in recv:
+                recv[key] = [torch.empty_like(last) for _ in range(world)]
+            bufs = recv[key]
         dist.gather(last, bufs, dst=0)
         return last
+
+    def gather_lanes(parts):
+        """free-running lanes: every lane hands its finished images to the gather on ITS stream, in lane order on all
+        ranks; the lane's next replay is ordered after its gather by the stream, nothing waits on the host"""
+        for lane, (_, imgs, st) in enumerate(parts):
+            with torch.cuda.stream(st):
+                gather(imgs[-1], lane)
 
     # one-time setup, not a benchmark step: the first two calls size the workspaces and capture the decode-loop
     # graph of every lane (eager pass, capture pass); afterwards every call is a pure replay
@@ -263,17 +282,22 @@ def main():
         step(-1 - i)
     torch.cuda.synchronize(device)
     log("warm-up")
+    free_running = getattr(step, "joins", False) and STREAMS > 1
     for i in range(args.warmup):
-        gather(step(i))
+        if free_running and dist is not None:
+            gather_lanes(step(i, join=False))           # same code path as the timed loop (RCCL init, receive buffers)
+        else:
+            gather(step(i))
     log("timed region")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
-    free_running = dist is None and getattr(step, "joins", False) and STREAMS > 1
     t0 = time.perf_counter()
     for i in range(args.steps):
         if free_running:
-            step(args.warmup + i, join=False)     # lanes keep their own stream order; device-wide sync below joins them
+            parts = step(args.warmup + i, join=False)   # lanes keep their own stream order; device-wide sync below joins them
+            if dist is not None:
+                gather_lanes(parts)
         else:
             gather(step(args.warmup + i))
     torch.cuda.synchronize(device)
@@ -348,11 +372,17 @@ def main():
         result["extra"] = {"final_decode_only_images_per_s": round(3 * B / (time.perf_counter() - t1), 2)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload)
-    if rank == 0:
-        print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes its version banner to the C stdout buffer; push that out first so the JSON line is the last line
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
