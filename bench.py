@@ -36,6 +36,7 @@ from paintmind_amd.ops import swiglu_hidden  # noqa: E402
 
 USE_GRAPH = os.environ.get("PM_BENCH_NO_GRAPH", "0") != "1"   # decode loop = one replayed hipGraph (captured during warm-up)
 STREAMS = int(os.environ.get("PM_BENCH_STREAMS", "3"))   # concurrent micro-batches per GPU (1 = one stream)
+LANE_SPLIT = os.environ.get("PM_BENCH_LANE_SPLIT")       # development: explicit micro-batch sizes, e.g. "32,16,16"
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
@@ -116,13 +117,16 @@ def make_step(workload, model, device, rank, decode_every_step=True):
 
     def step(i, join=True, streams=None):
         STREAMS = globals()["STREAMS"] if streams is None else streams
+        lanes = STREAMS
+        if LANE_SPLIT and STREAMS > 1:
+            lanes = tuple(int(x) for x in LANE_SPLIT.split(","))
         # join=False (single-GPU timed loop): the micro-batch lanes are not joined between steps, so consecutive
         # steps pipeline across lanes; the caller joins once before the closing synchronize
         if STREAMS > 1 and not join:
             return pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=1000 + i, image_base=rank * B, use_graph=USE_GRAPH,
-                                     streams=STREAMS, join=False, wait_current=False)
+                                     streams=lanes, join=False, wait_current=False)
         ids, imgs = pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=1000 + i, image_base=rank * B, use_graph=USE_GRAPH,
-                                      streams=STREAMS, wait_current=False)
+                                      streams=lanes, wait_current=False)
         return imgs[-1]
     step.joins = True
     return step

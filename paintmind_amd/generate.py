@@ -187,7 +187,7 @@ class Pipeline(nn.Module):
                      join=True, wait_current=True):
         """The decode loop on device tensors: returns (ids [B,N], imgs [n_decoded,B,C,H,W] or None).
 
-        streams > 1: the batch is cut into that many contiguous micro-batches that run CONCURRENTLY on separate HIP
+        streams > 1 (or a tuple of micro-batch sizes): the batch is cut into contiguous micro-batches that run CONCURRENTLY on separate HIP
         streams (own native handle + workspace each, same weights): memory-bound kernels of one micro-batch overlap
         the MFMA-bound kernels of another.  The sampling RNG is keyed by the global image index, so the result is
         identical to streams=1.
@@ -196,7 +196,15 @@ class Pipeline(nn.Module):
         (only valid when `context` is None or was produced before the lanes last synchronised with it)."""
         eng = self.engine()
         temps, nmask = self._schedule(timesteps, temperature)
-        streams = max(1, min(int(streams), B))
+        if isinstance(streams, (list, tuple)):           # explicit micro-batch sizes, e.g. (32, 16, 16)
+            sizes = [int(x) for x in streams]
+            if sum(sizes) != B or min(sizes) < 1:
+                raise ValueError(f"micro-batch sizes {sizes} must be positive and sum to the batch size {B}")
+            bounds = [(sum(sizes[:i]), sum(sizes[:i + 1])) for i in range(len(sizes))]
+            streams = len(sizes)
+        else:
+            streams = max(1, min(int(streams), B))
+            bounds = None
         if streams == 1:
             ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
             return eng.generate(self.vqgan.engine(), ids, context, temps, nmask, decode_flags, topk, seed=seed,
@@ -208,7 +216,7 @@ class Pipeline(nn.Module):
             ready.record(cur)
         parts = []
         for i, (e, v, st) in enumerate(self._lanes(streams)):
-            lo, hi = shard_range(B, i, streams)
+            lo, hi = bounds[i] if bounds is not None else shard_range(B, i, streams)
             if wait_current:
                 st.wait_event(ready)
             with torch.cuda.stream(st):

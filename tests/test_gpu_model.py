@@ -175,6 +175,10 @@ def test_generate_concurrent_micro_batches_match_single_stream(tiny_pipe):
             many = pipe.generate(texts, timesteps=5, topk=3, save_interval=1, seed=11, return_ids=True, streams=k, use_graph=graph)
             assert torch.equal(many[1], one[1]), (k, graph)
             assert all(torch.equal(a, b) for a, b in zip(many[0], one[0])), (k, graph)
+    uneven = pipe.generate(texts, timesteps=5, topk=3, save_interval=1, seed=11, return_ids=True, streams=(1, 3, 1))
+    assert torch.equal(uneven[1], one[1]) and all(torch.equal(a, b) for a, b in zip(uneven[0], one[0]))
+    with pytest.raises(ValueError):
+        pipe.generate(texts, timesteps=5, topk=3, save_interval=1, seed=11, streams=(2, 2))
 
 
 def test_reconstruction_figure(tmp_path):
