@@ -59,6 +59,23 @@ def test_gemm_large_tile_kernel_with_residual():
     assert rel_err(out, a @ w.T + b + pos[np.arange(M) % 1024]) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(65536, 512, 512), (32768, 768, 768), (49152, 1024, 64)])
+def test_gemm_two_workgroup_kernel_short_k_residual(M, N, K):
+    """f32-out residual GEMMs with K < 1024 and >= 192 tiles of 256x128 (the attention out-projections at bench batch
+    sizes) take gemm2b.hip; full residual and row-modulo residual (position embedding) against the oracle"""
+    a, w, b = bf16_round(rnd(M, K)), bf16_round(rnd(N, K, scale=K ** -0.5)), rnd(N)
+    r = rnd(M, N)
+    out = n(ops.gemm(t(a, torch.bfloat16), t(w, torch.bfloat16), bias=t(b), residual=t(r), out_dtype=torch.float32))
+    ref = a @ w.T + b
+    assert rel_err(out, ref + r) < 2e-5
+    assert np.abs(out - (ref + r)).reshape(M // 256, 256, N // 128, 128).max(axis=(1, 3)).max() < 1e-3
+    pos = rnd(1024, N)
+    out = n(ops.gemm(t(a, torch.bfloat16), t(w, torch.bfloat16), bias=t(b), residual=t(pos), res_rows=1024, out_dtype=torch.float32))
+    assert rel_err(out, ref + pos[np.arange(M) % 1024]) < 2e-5
+    out = n(ops.gemm(t(a, torch.bfloat16), t(w, torch.bfloat16), residual=t(r), out_dtype=torch.float32))      # no bias
+    assert rel_err(out, a @ w.T + r) < 2e-5
+
+
 def test_swiglu_and_heads_large_tile_kernel():
     M, D, H = 16384, 512, 1368
     lin = torch.nn.Linear(D, 2 * H)
