@@ -114,32 +114,32 @@ __device__ __forceinline__ void k_loop(const LoopCtx& c, unsigned char* lds, f32
         const unsigned ba0 = c.lds_base + boff + c.fa0, ba1 = c.lds_base + boff + c.fa1;
         const unsigned bw0 = c.lds_base + boff + c.fw0, bw1 = c.lds_base + boff + c.fw1;
         unsigned char* nxt = lds + ((kt + 1) & 1) * BUF_BYTES;
+        // Every wave issues its DMA piece in ITS fragment-read slot (lead: first slot, lag: second slot), i.e. while the
+        // other wave of the SIMD runs MFMAs: a DMA instruction holds the issuing wave for ~60 cycles, which in front of
+        // the lag wave's MFMAs (with the lead wave busy reading) would idle the matrix pipe.  The piece still precedes
+        // the phase's WAIT, so the vmcnt arithmetic is the same for both roles.
         // ---------------- phase 1: A rows [0,64) x W rows [0,32)
-        ISSUE(PA0)
-        if constexpr (LEAD) { RD_A(0) RD_W(0) LGKM0; } else { if (kt > 0) MMA(1, 0) }
+        if constexpr (LEAD) { ISSUE(PA0) RD_A(0) RD_W(0) LGKM0; } else { if (kt > 0) MMA(1, 0) }
         BAR;
-        if constexpr (LEAD) { MMA(0, 0) } else { RD_A(0) RD_W(0) LGKM0; }
+        if constexpr (LEAD) { MMA(0, 0) } else { ISSUE(PA0) RD_A(0) RD_W(0) LGKM0; }
         WAIT(2)
         BAR;
         // ---------------- phase 2: A rows [0,64) x W rows [32,64)
-        ISSUE(PW0)
-        if constexpr (LEAD) { RD_W(1) LGKM0; } else { MMA(0, 0) }
+        if constexpr (LEAD) { ISSUE(PW0) RD_W(1) LGKM0; } else { MMA(0, 0) }
         BAR;
-        if constexpr (LEAD) { MMA(0, 1) } else { RD_W(1) LGKM0; }
+        if constexpr (LEAD) { MMA(0, 1) } else { ISSUE(PW0) RD_W(1) LGKM0; }
         WAIT(0)
         BAR;
         // ---------------- phase 3: A rows [64,128) x W rows [32,64)
-        ISSUE(PW1)
-        if constexpr (LEAD) { RD_A(1) LGKM0; } else { MMA(0, 1) }
+        if constexpr (LEAD) { ISSUE(PW1) RD_A(1) LGKM0; } else { MMA(0, 1) }
         BAR;
-        if constexpr (LEAD) { MMA(1, 1) } else { RD_A(1) LGKM0; }
+        if constexpr (LEAD) { MMA(1, 1) } else { ISSUE(PW1) RD_A(1) LGKM0; }
         WAIT(-1)
         BAR;
         // ---------------- phase 4: A rows [64,128) x W rows [0,32) (re-read: cheaper than 16 more live registers)
-        ISSUE(PA1)
-        if constexpr (LEAD) { RD_W(0) LGKM0; } else { MMA(1, 1) }
+        if constexpr (LEAD) { ISSUE(PA1) RD_W(0) LGKM0; } else { MMA(1, 1) }
         BAR;
-        if constexpr (LEAD) { MMA(1, 0) } else { RD_W(0) LGKM0; }
+        if constexpr (LEAD) { MMA(1, 0) } else { ISSUE(PA1) RD_W(0) LGKM0; }
         WAIT(-1)
         BAR;
     }
