@@ -164,8 +164,13 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
 #pragma unroll
         for (int j = 0; j < QF; ++j) o[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float mrun[QF], lrun[QF];            // running max; per-lane partial row sums (reduced at the end)
+    // The S^T accumulators START from -m (the running max of their query column) instead of 0, so the MFMA delivers
+    // s - m and the softmax needs no subtraction per score.  m is the value at the time the QK^T of a half-tile is
+    // issued; the (rare) rescale branch below moves already-computed scores to a new max.  Before the first
+    // half-tile m is undefined and the accumulators start from 0.
+    f32x4_t negm[QF];
 #pragma unroll
-    for (int j = 0; j < QF; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; }
+    for (int j = 0; j < QF; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; negm[j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
     const int ntiles = (Nkv + KT - 1) / KT;
     const int nhalves = (Nkv + 31) / 32;                     // 32-key half-tiles that contain at least one valid key
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int qf = 0; qf < QF; ++qf) sd[kk][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int qf = 0; qf < QF; ++qf) sd[kk][qf] = negm[qf];
             const int krow = key_of_row<T>(2 * pc + kk, l15);
 #pragma unroll
             for (int c = 0; c < C::NCH; ++c) {
@@ -205,23 +210,31 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
                     }
                 }
         }
-        float tmax[QF];
-        bool grow = false;
+        float tmax[QF];                                      // max of (s - mb), mb = what the accumulators started from
+        const bool first = (hh == 0);
+        bool grow = first;
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
             float m = vmax3(sc[0][qf][0], sc[0][qf][1], sc[0][qf][2]);
             m = vmax3(m, sc[0][qf][3], sc[1][qf][0]);
             m = vmax3(m, sc[1][qf][1], sc[1][qf][2]);
-            m = group4_max(vmax2(m, sc[1][qf][3]));
+            m = vmax2(m, sc[1][qf][3]);                      // this lane's 8 keys only: enough to DETECT growth
             tmax[qf] = m;
-            grow |= (m - mrun[qf] > kDefer);                 // first half-tile: mrun = -inf -> true
+            grow |= (m > kDefer);
         }
         if (__any(grow)) {                                   // wave-uniform: rescale everything at the old max exactly once
 #pragma unroll
             for (int qf = 0; qf < QF; ++qf) {
-                const float mnew = vmax3(mrun[qf], tmax[qf], -1e30f);
+                const float mb = first ? 0.f : mrun[qf];
+                const float mnew = vmax3(mrun[qf], group4_max(tmax[qf]) + mb, -1e30f);   // column max over the 4 lane groups
                 const float alpha = EXP2 ? __builtin_amdgcn_exp2f(mrun[qf] - mnew) : expf(mrun[qf] - mnew);
+                const float delta = mb - mnew;               // scores already hold s - mb: move them to s - mnew
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[kk][qf][r] += delta;
                 mrun[qf] = mnew;
+                negm[qf] = f32x4_t{-mnew, -mnew, -mnew, -mnew};
                 lrun[qf] *= alpha;
 #pragma unroll
                 for (int df = 0; df < 4; ++df) {
@@ -239,13 +252,12 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
         if constexpr (has_next) qk_half(sn, hn);
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
-            const float m = mrun[qf];
             float psum = 0.f;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = EXP2 ? __builtin_amdgcn_exp2f(sc[kk][qf][r] - m) : expf(sc[kk][qf][r] - m);
+                    const float pv = EXP2 ? __builtin_amdgcn_exp2f(sc[kk][qf][r]) : expf(sc[kk][qf][r]);   // sc = s - m
                     sc[kk][qf][r] = pv;
                     psum += pv;
                 }
@@ -261,12 +273,12 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
         }
         if constexpr (sizeof(T) == 2 && EXP2 && has_next) {
             {
-                // 4 K-fragment reads, then 16 x {1 MFMA, 5 VALU, 2 transcendental}
+                // 4 K-fragment reads, then 16 x {1 MFMA, 2 transcendental}; the pack / row-sum VALU depend on exps of later groups
+                // and are left to the scheduler (a VALU group inside the pattern makes it infeasible and it is dropped whole)
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
                     __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
                 }
             }
