@@ -139,8 +139,17 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             }
         }
     }
-    float4 sb[4] = {};                                             // SwiGLU: this lane's bias slices (x1 | x2, 8 each)
-    if constexpr (EPI == EPI_SWIGLU) {
+    // SwiGLU.  The wave's 64 columns are [x1 0-15 | x2 0-15 | x1 16-31 | x2 16-31] of 32 hidden columns, so in the
+    // ACCUMULATOR layout lane (l15, g) already holds x1 and x2 of the same hidden columns (tiles 0|1 and 2|3).
+    //   bf16 out: gate in registers, then transpose 32 bf16 columns per row (a quarter of the fp32 traffic);
+    //   f32 out (verify mode): generic fp32 transposition first, gate on the transposed rows.
+    constexpr bool GATE_IN_REGS = (EPI == EPI_SWIGLU) && sizeof(OutT) == 2;
+    float4 sb[4] = {};                                             // this lane's bias slices
+    if constexpr (GATE_IN_REGS) {
+        const float* b1 = p.bias + nw + g * 4;                     // x1 lo | x2 lo | x1 hi | x2 hi, columns g*4 .. g*4+3
+        sb[0] = *reinterpret_cast<const float4*>(b1);      sb[1] = *reinterpret_cast<const float4*>(b1 + 16);
+        sb[2] = *reinterpret_cast<const float4*>(b1 + 32); sb[3] = *reinterpret_cast<const float4*>(b1 + 48);
+    } else if constexpr (EPI == EPI_SWIGLU) {
         const int q = lane & 3;
         const float* b1 = p.bias + nw + (q >> 1) * 32 + (q & 1) * 8;
         sb[0] = *reinterpret_cast<const float4*>(b1);      sb[1] = *reinterpret_cast<const float4*>(b1 + 4);
@@ -171,12 +180,35 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                         p.residual + (size_t)((mwave + (mi + 1) * 16 + it * RPI + lane / LPR) % p.res_rows) * p.ldr + ncol);
             }
         }
+        const int mbase = mwave + mi * 16;
+        if constexpr (GATE_IN_REGS) {
+            constexpr int RS = 80;                                 // bytes per staged row: 32 bf16 + pad, 16-B aligned
+            unsigned char* row = eraw + l15 * RS;
+            *reinterpret_cast<uint2*>(row + g * 8) = make_uint2(
+                pack_bf16x2(silu_mul(acc[mi][0][0] + sb[0].x, acc[mi][1][0] + sb[1].x, p.fast_math),
+                            silu_mul(acc[mi][0][1] + sb[0].y, acc[mi][1][1] + sb[1].y, p.fast_math)),
+                pack_bf16x2(silu_mul(acc[mi][0][2] + sb[0].z, acc[mi][1][2] + sb[1].z, p.fast_math),
+                            silu_mul(acc[mi][0][3] + sb[0].w, acc[mi][1][3] + sb[1].w, p.fast_math)));
+            *reinterpret_cast<uint2*>(row + 32 + g * 8) = make_uint2(
+                pack_bf16x2(silu_mul(acc[mi][2][0] + sb[2].x, acc[mi][3][0] + sb[3].x, p.fast_math),
+                            silu_mul(acc[mi][2][1] + sb[2].y, acc[mi][3][1] + sb[3].y, p.fast_math)),
+                pack_bf16x2(silu_mul(acc[mi][2][2] + sb[2].z, acc[mi][3][2] + sb[3].z, p.fast_math),
+                            silu_mul(acc[mi][2][3] + sb[2].w, acc[mi][3][3] + sb[3].w, p.fast_math)));
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int erow = lane >> 2, q = lane & 3, m = mbase + erow;
+            if (FULL || m < p.M)                                   // 4 lanes x 16 B = the row's 32 hidden columns
+                *reinterpret_cast<uint4*>(reinterpret_cast<OutT*>(p.out) + (size_t)m * p.ldo + (nw >> 1) + q * 8) =
+                    *reinterpret_cast<const uint4*>(eraw + erow * RS + q * 16);
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
             *reinterpret_cast<f32x4_t*>(ebuf + l15 * ESTRIDE + ni * 16 + g * 4) = acc[mi][ni];
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int mbase = mwave + mi * 16;
         if constexpr (EPI == EPI_STD) {
             // one store instruction = RPI rows x 64 columns, LPR adjacent lanes per row (full 128-B lines)
 #pragma unroll
