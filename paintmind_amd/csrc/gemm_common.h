@@ -204,6 +204,34 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             continue;
         }
+        if constexpr (EPI == EPI_HEADS && sizeof(OutT) == 2) {
+            // Q / K part, bf16: scale and round in registers, transpose 64 bf16 columns per row (half the fp32 traffic)
+            constexpr int RS = 144;                                // bytes per staged row: 64 bf16 + pad, 16-B aligned
+            const int part = nw / p.inner;
+            const int h = (nw % p.inner) >> 6;
+            const int kind = p.kinds[part];
+            OutT* dst = reinterpret_cast<OutT*>(p.outs[part]);
+            const int tstride = kind == PMHIP_PART_Q ? p.tokens : p.tokens_pad;
+            const float sc = kind == PMHIP_PART_Q ? p.q_scale : 1.0f;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<uint2*>(eraw + l15 * RS + ni * 32 + g * 8) =
+                    make_uint2(pack_bf16x2(acc[mi][ni][0] * sc, acc[mi][ni][1] * sc), pack_bf16x2(acc[mi][ni][2] * sc, acc[mi][ni][3] * sc));
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {                       // 8 rows x 128 B per store instruction
+                const int r = it * 8 + (lane >> 3), mm = mbase + r, c16 = lane & 7;
+                if (FULL || mm < p.M) {
+                    const int b = mm / p.tokens, t = mm % p.tokens;
+                    *reinterpret_cast<uint4*>(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + c16 * 8) =
+                        *reinterpret_cast<const uint4*>(eraw + r * RS + c16 * 16);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
             *reinterpret_cast<f32x4_t*>(ebuf + l15 * ESTRIDE + ni * 16 + g * 4) = acc[mi][ni];
