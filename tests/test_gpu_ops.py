@@ -159,6 +159,53 @@ def test_heads_projection_and_attention(dtype, B, heads, Nq, Nkv):
     assert rel_err(out, ref) < (3e-5 if dtype == torch.float32 else 3e-2), rel_err(out, ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pattern", ["rising", "falling", "spikes", "huge_jumps", "very_negative"])
+def test_attention_running_max_rescale_paths(dtype, pattern):
+    """Scores whose maximum keeps growing along the key axis (every deferred-rescale branch of the online softmax fires,
+    including jumps far beyond the exp2 range), shrinking, with isolated spikes, and all very negative."""
+    B, H, Nq, Nkv = 1, 2, 256, 416                       # 6.5 tiles: ragged last tile, odd number of half-tiles
+    rng = np.random.default_rng(7)
+    q = rng.standard_normal((B, H, Nq, 64)).astype(np.float32)
+    k = rng.standard_normal((B, H, Nkv, 64)).astype(np.float32) * 0.3
+    v = rng.standard_normal((B, H, Nkv, 64)).astype(np.float32)
+    qdir = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    ramp = np.linspace(0.0, 1.0, Nkv, dtype=np.float32)
+    if pattern == "rising":
+        boost = 60.0 * ramp                               # score of key j grows steadily: max moves at almost every tile
+    elif pattern == "falling":
+        boost = 60.0 * (1 - ramp)
+    elif pattern == "spikes":
+        boost = np.where(rng.random(Nkv) < 0.03, 45.0, 0.0).astype(np.float32)
+    elif pattern == "huge_jumps":
+        boost = (np.arange(Nkv) // 50).astype(np.float32) * 1500.0     # score jumps of several hundred (exp2 domain) every 50 keys
+    else:
+        boost = np.full(Nkv, -400.0, dtype=np.float32)
+    # add boost_j along the mean query direction of each head: s_ij gains ~ boost_j * |q_i| * cos(...)
+    mean_dir = qdir.mean(axis=2, keepdims=True)
+    mean_dir /= np.linalg.norm(mean_dir, axis=-1, keepdims=True)
+    k = k + boost[None, None, :, None] * mean_dir
+    if dtype == torch.bfloat16:
+        q, k, v = map(bf16_round, (q, k, v))
+    scale = 0.125
+    s = (q.astype(np.float64) * scale) @ k.astype(np.float64).transpose(0, 1, 3, 2)
+    s -= s.max(-1, keepdims=True)
+    pr = np.exp(s)
+    pr /= pr.sum(-1, keepdims=True)
+    ref = (pr @ v.astype(np.float64)).transpose(0, 2, 1, 3).reshape(B * Nq, H * 64)
+    fast = dtype == torch.bfloat16
+    nkp = 448
+    kp = np.zeros((B, H, nkp, 64), np.float32)
+    kp[:, :, :Nkv] = k
+    vtp = np.zeros((B, H, 64, nkp), np.float32)
+    vtp[:, :, :, :Nkv] = v.transpose(0, 1, 3, 2)
+    out = n(ops.attention(t(q * (scale * (ops.LOG2E if fast else 1.0)), dtype), t(kp, dtype), t(vtp, dtype), Nkv, use_exp2=fast))
+    assert np.isfinite(out).all()
+    # scores of ~1e4 carry an fp32 ulp of ~1e-3 themselves: any fp32 softmax is only that accurate against float64
+    tol32 = 2e-3 if pattern == "huge_jumps" else 5e-5
+    assert rel_err(out, ref) < (tol32 if dtype == torch.float32 else 4e-2), rel_err(out, ref)
+
+
 def test_attention_ignores_garbage_in_padding():
     """K rows / V^T columns beyond Nkv may hold anything (NaN included)."""
     B, H, Nq, Nkv = 1, 2, 64, 77
