@@ -185,21 +185,25 @@ def test_attention_running_max_rescale_paths(dtype, pattern):
     mean_dir = qdir.mean(axis=2, keepdims=True)
     mean_dir /= np.linalg.norm(mean_dir, axis=-1, keepdims=True)
     k = k + boost[None, None, :, None] * mean_dir
-    if dtype == torch.bfloat16:
-        q, k, v = map(bf16_round, (q, k, v))
     scale = 0.125
-    s = (q.astype(np.float64) * scale) @ k.astype(np.float64).transpose(0, 1, 3, 2)
+    fast = dtype == torch.bfloat16
+    if fast:                                              # the kernel sees q pre-scaled by scale*log2(e), rounded ONCE
+        k, v = bf16_round(k), bf16_round(v)
+        qs = bf16_round(q * (scale * ops.LOG2E))
+        s = (qs.astype(np.float64) @ k.astype(np.float64).transpose(0, 1, 3, 2)) * np.log(2.0)
+    else:
+        qs = q * np.float32(scale)
+        s = qs.astype(np.float64) @ k.astype(np.float64).transpose(0, 1, 3, 2)
     s -= s.max(-1, keepdims=True)
     pr = np.exp(s)
     pr /= pr.sum(-1, keepdims=True)
     ref = (pr @ v.astype(np.float64)).transpose(0, 2, 1, 3).reshape(B * Nq, H * 64)
-    fast = dtype == torch.bfloat16
     nkp = 448
     kp = np.zeros((B, H, nkp, 64), np.float32)
     kp[:, :, :Nkv] = k
     vtp = np.zeros((B, H, 64, nkp), np.float32)
     vtp[:, :, :, :Nkv] = v.transpose(0, 1, 3, 2)
-    out = n(ops.attention(t(q * (scale * (ops.LOG2E if fast else 1.0)), dtype), t(kp, dtype), t(vtp, dtype), Nkv, use_exp2=fast))
+    out = n(ops.attention(t(qs, dtype), t(kp, dtype), t(vtp, dtype), Nkv, use_exp2=fast))
     assert np.isfinite(out).all()
     # scores of ~1e4 carry an fp32 ulp of ~1e-3 themselves: any fp32 softmax is only that accurate against float64
     tol32 = 2e-3 if pattern == "huge_jumps" else 5e-5
