@@ -98,6 +98,8 @@ namespace {
 struct Workspace {
     std::map<std::string, std::pair<void*, size_t>> bufs;
     bool frozen = false;   // set while a graph capture is in flight: growing would be a bug
+    uint64_t gen = 0;      // bumped by every (re)allocation: a captured graph holds raw buffer pointers and is only
+                           // valid for the generation it was captured at
     ~Workspace() {
         for (auto& kv : bufs)
             if (kv.second.first) (void)hipFree(kv.second.first);
@@ -119,6 +121,7 @@ struct Workspace {
                 return PMHIP_ENOMEM;
             }
             e.second = want;
+            ++gen;
         }
         *out = e.first;
         return PMHIP_OK;
@@ -207,7 +210,9 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
 // ------------------------------------------------------------------------------------------------
 // VQModel
 // ------------------------------------------------------------------------------------------------
+static uint64_t g_next_vq_uid = 1;
 struct pmhip_vqgan {
+    uint64_t uid = g_next_vq_uid++;     // graph keys name the handle by this, never by its (reusable) heap address
     int device = 0, dtype = 0;
     pmhip_vqgan_cfg cfg{};
     pmhip_vqgan_weights w{};
@@ -367,6 +372,7 @@ extern "C" int pmhip_vqgan_decoder_forward(pmhip_vqgan* h, const float* x, int B
 struct GraphEntry {
     bool warmed = false;            // one eager pass has sized every workspace buffer
     hipGraphExec_t exec = nullptr;
+    uint64_t s2_gen = 0, vq_gen = 0;   // workspace generations the graph's baked-in pointers belong to
 };
 
 struct pmhip_s2 {
@@ -549,7 +555,7 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
     PM_HIP(hipMemcpyAsync(gids, ids, ids_bytes, hipMemcpyDeviceToDevice, s));
 
     std::string key = "B" + std::to_string(B) + "T" + std::to_string(T) + "k" + std::to_string(topk) + "L" +
-                      std::to_string(context ? L : 0) + "v" + std::to_string((size_t)vq) + "d";
+                      std::to_string(context ? L : 0) + "v" + std::to_string(vq ? vq->uid : 0) + "d";
     for (int t = 0; t < T; ++t) key += (decode_host && decode_host[t]) ? '1' : '0';
     GraphEntry& ge = s2->graphs[key];
 
@@ -566,6 +572,13 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
         PM_TRY(run_steps(s));                                  // eager once: sizes every workspace buffer
         ge.warmed = true;
     } else {
+        // a workspace buffer of either handle was reallocated since the capture (a later call with a larger batch, a
+        // longer context, a direct encode/decode on the shared vqgan handle ...): the graph's pointers are stale
+        if (ge.exec && (ge.s2_gen != s2->ws.gen || (vq && ge.vq_gen != vq->ws.gen))) {
+            PM_HIP(hipStreamSynchronize(s));                  // an earlier replay may still be running
+            (void)hipGraphExecDestroy(ge.exec);
+            ge.exec = nullptr;
+        }
         if (!ge.exec) {
             if (!s2->capture_stream) PM_HIP(hipStreamCreateWithFlags(&s2->capture_stream, hipStreamNonBlocking));
             hipStream_t cap = s2->capture_stream;
@@ -585,6 +598,8 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
             rc = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             PM_HIP(rc);
+            ge.s2_gen = s2->ws.gen;
+            ge.vq_gen = vq ? vq->ws.gen : 0;
         }
         PM_HIP(hipGraphLaunch(ge.exec, s));
     }

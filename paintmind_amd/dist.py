@@ -23,6 +23,8 @@ def gather_images(local, counts, dst=0, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nmax = max(counts)
+    if local.is_cuda and dist.get_backend(group) != "nccl":
+        local = local.cpu()                     # gloo groups (CPU tests, ranks sharing one GPU) exchange host tensors
     pad = local
     if local.shape[0] < nmax:
         pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -34,22 +36,44 @@ def gather_images(local, counts, dst=0, group=None):
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
-def generate_sharded(pipe, text, seed, group=None, dst=0, **kwargs):
+def generate_sharded(pipe, text, seed, group=None, dst=0, timesteps=18, save_interval=2, **kwargs):
     """Pipeline.generate over a prompt list sharded across the process group.
 
     Returns on rank `dst` the same list-of-tensors structure the single-process call returns for the full
-    prompt list (bit-identical for the same seed); other ranks get None."""
+    prompt list (bit-identical for the same seed); other ranks get None.
+
+    Every rank issues the SAME number of gathers: it depends only on (timesteps, save_interval), the steps whose
+    image Pipeline.generate returns (generate.py:195-196).  A rank whose shard is empty (fewer prompts than ranks)
+    contributes zero-row tensors of the agreed image shape instead of skipping the collective."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     counts = [shard_range(len(text), r, world)[1] - shard_range(len(text), r, world)[0] for r in range(world)]
     lo, hi = shard_range(len(text), rank, world)
+    n_out = sum(1 for step in range(timesteps) if step % save_interval == 0)
+    if len(text) == 0:
+        return [] if rank == dst else None
     tm = getattr(pipe, "text_model", None)
     if tm is not None and hasattr(tm, "base_index"):
         tm.base_index = lo                                   # synthetic text features are keyed by global index
-    imgs = pipe.generate(text[lo:hi], seed=seed, image_base=lo, keep_on_device=True, **kwargs) if hi > lo else []
-    n_out = torch.tensor([len(imgs)], dtype=torch.int64, device=imgs[0].device if imgs else "cpu")
+    imgs = []
+    if hi > lo:
+        imgs = pipe.generate(text[lo:hi], timesteps=timesteps, save_interval=save_interval, seed=seed, image_base=lo,
+                             keep_on_device=True, **kwargs)
+        if len(imgs) != n_out:
+            raise RuntimeError(f"generate returned {len(imgs)} images, the schedule implies {n_out}")
+    if min(counts) == 0:
+        # the empty ranks need the image shape to pad with: agreed through one small all_gather that EVERY rank joins
+        # (rank-local facts must never decide how many collectives a rank issues)
+        on = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        tail = list(imgs[0].shape[1:]) if imgs else []
+        info = torch.tensor([len(tail)] + tail + [0] * (7 - len(tail)), dtype=torch.int64, device=on)
+        allinfo = [torch.empty_like(info) for _ in range(world)]
+        dist.all_gather(allinfo, info, group=group)
+        src = next(a for a, c in zip(allinfo, counts) if c > 0).cpu().tolist()
+        if not imgs:
+            imgs = [torch.zeros([0] + src[1:1 + src[0]], dtype=torch.float32, device=on) for _ in range(n_out)]
     out = []
-    for t in range(int(n_out.item())):
+    for t in range(n_out):
         g = gather_images(imgs[t], counts, dst=dst, group=group)
         out.append(g.cpu() if g is not None else None)
     return out if rank == dst else None

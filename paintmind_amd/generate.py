@@ -24,6 +24,11 @@ def exists(x):
     return x is not None
 
 
+def _draw_seed():
+    """a Philox seed from the torch CPU generator: governed by torch.manual_seed like the reference's noise"""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
 def mask_schedule(ratio):
     """cosine schedule, evaluated in float64 like the reference (generate.py:25-26)."""
     return np.cos(math.pi / 2. * ratio)
@@ -147,14 +152,18 @@ class Pipeline(nn.Module):
         return rows.reshape(ids.shape + (table.shape[1],))
 
     @torch.no_grad()
-    def sample(self, ids, mask_ratio, text=None, topk=1, temperature=1, noise=None, seed=0, step=0, image_base=0):
+    def sample(self, ids, mask_ratio, text=None, topk=1, temperature=1, noise=None, seed=None, step=0, image_base=0):
         """One MaskGIT step (generate.py:159-181) -> (ids', img).
 
         ``noise``: optional uniform(0,1) tensor shaped like the logits (B,N,V) -- the parity hook for the
         reference's ``torch.zeros_like(t).uniform_(0,1)``; without it a counter-based Philox stream keyed
-        by (seed, step, image_base + image index, position, class) is used.
+        by (seed, step, image_base + image index, position, class) is used.  ``seed=None`` draws a fresh
+        seed from the torch generator on every call, like the reference's fresh global-RNG noise
+        (generate.py:40-46), so a caller looping over sample() never reuses uniforms.
         """
         nm = num_token_masked(mask_ratio, self.num_tokens)
+        if seed is None:
+            seed = _draw_seed()
         eng = self.engine()
         ids = ids.to(eng.device, torch.int64).clone().contiguous()
         ids, img, _, _ = eng.sample(self.vqgan.engine(), ids, text, topk, temperature, nm, noise=noise, seed=seed, step=step,
@@ -248,7 +257,7 @@ class Pipeline(nn.Module):
         context = self.text_model(text)
         eng = self.engine()
         if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # governed by torch.manual_seed like the reference
+            seed = _draw_seed()
         flags = [step % save_interval == 0 for step in range(timesteps)]
         # use_graph: the T-step loop is captured into one hipGraph (first call eager, second call captures, later
         # calls replay); per-call scalars (seed, schedule values) are read from device memory, so one graph serves all
@@ -259,7 +268,9 @@ class Pipeline(nn.Module):
         out = [] if imgs is None else [im if keep_on_device else im.cpu() for im in imgs]
         return (out, ids) if return_ids else out
 
-    def _region_loop(self, img, coord, text, timesteps, topk, temperature, keep_inside):
+    def _region_loop(self, img, coord, text, timesteps, topk, temperature, keep_inside, seed=None):
+        if seed is None:
+            seed = _draw_seed()                 # one stream per call; the step index separates the steps
         z, ids, text = self.to_latent(img, text)
         s = self.patch_size
         x, y, h, w = coord[0] // s, coord[1] // s, coord[2] // s, coord[3] // s
@@ -276,15 +287,15 @@ class Pipeline(nn.Module):
             progress = (step + 1) / timesteps
             masked_r = mask_schedule(progress)
             cur_temp = temperature * (1 - step / timesteps)
-            ids, out = self.sample(ids, mask_ratio=masked_r, text=text, topk=topk, temperature=cur_temp, step=step)
+            ids, out = self.sample(ids, mask_ratio=masked_r, text=text, topk=topk, temperature=cur_temp, seed=seed, step=step)
         return out
 
     @torch.no_grad()
-    def inpaint(self, img, coord, text=None, timesteps=1, topk=1, temperature=0):
+    def inpaint(self, img, coord, text=None, timesteps=1, topk=1, temperature=0, seed=None):
         """re-generate the rectangle coord=(x,y,h,w) in pixels (generate.py:200-217)."""
-        return self._region_loop(img, coord, text, timesteps, topk, temperature, keep_inside=False)
+        return self._region_loop(img, coord, text, timesteps, topk, temperature, keep_inside=False, seed=seed)
 
     @torch.no_grad()
-    def outpaint(self, img, coord, text=None, timesteps=1, topk=1, temperature=0):
+    def outpaint(self, img, coord, text=None, timesteps=1, topk=1, temperature=0, seed=None):
         """keep the rectangle, re-generate everything else (generate.py:219-236)."""
-        return self._region_loop(img, coord, text, timesteps, topk, temperature, keep_inside=True)
+        return self._region_loop(img, coord, text, timesteps, topk, temperature, keep_inside=True, seed=seed)

@@ -64,7 +64,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("n_prompts", [5, 8])
+@pytest.mark.parametrize("n_prompts", [1, 5, 8])       # 1 prompt on 2 ranks: rank 1 has an empty shard
 def test_sharded_generate_matches_single_process(n_prompts):
     world = 2
     ctx = mp.get_context("spawn")
