@@ -2,6 +2,7 @@
 """Headline benchmark: 256x256 images/sec/GPU, 8-step MaskGIT decode with vit-s-vqgan tokens.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N ...            (no WORLD_SIZE in the environment: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,26 +14,24 @@ reference does per generate() (generate.py:165; nothing is skipped).  Images sta
 Multi-GPU: weak scaling, every rank decodes its own 64 images (RNG keyed by global image index), no
 collective in the data path, one RCCL gather of the finished images to rank 0 inside the timed region.
 
+Before the timed region the exact timed configuration (bf16, hipGraph replay, concurrent micro-batch lanes)
+is checked once against the eager single-stream loop: ids and every decoded image must be bit-identical,
+otherwise no value is printed ("self_check").
+
 One JSON line is printed by rank 0; see DESIGN.md for how `roofline` and `cpu_baseline` are derived.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import paintmind_amd as pm  # noqa: E402
-from paintmind_amd import ops  # noqa: E402
-from paintmind_amd.config import ver2cfg  # noqa: E402
-from paintmind_amd.generate import Pipeline  # noqa: E402
-from paintmind_amd.ops import swiglu_hidden  # noqa: E402
 
 USE_GRAPH = os.environ.get("PM_BENCH_NO_GRAPH", "0") != "1"   # decode loop = one replayed hipGraph (captured during warm-up)
 STREAMS = int(os.environ.get("PM_BENCH_STREAMS", "3"))   # concurrent micro-batches per GPU (1 = one stream)
@@ -41,19 +40,61 @@ PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
+DEFAULT_WORKLOAD = "maskgit-uncond-12L-d512-T8"
 WORKLOADS = {
     # name: (pipeline config, batch per GPU, timesteps, context length or None)
     "maskgit-uncond-12L-d512-T8": ("bench-uncond-12L-d512", 64, 8, None),      # BASELINE configs[2]
     "maskgit-text-24L-d768-T8": ("bench-text-24L-d768", 32, 8, 77),            # north_star target model, 8 steps
     "maskgit-text-24L-d768-T12": ("bench-text-24L-d768", 32, 12, 77),          # BASELINE configs[3] per-GPU share
+    "maskgit-text-24L-d1024-512px-T18": ("bench-text-24L-d1024-512px", 64, 18, 77),   # BASELINE configs[4] per-GPU share
     "vit-s-recon": (None, 64, 0, None),                                         # BASELINE configs[1]
+    "launch-selftest": (None, 4, 0, None),     # no compute: exercises the rank launcher / gather / JSON relay on CPU (gloo)
 }
+# measured after the headline, outside its timed region, each with its own ms_per_step ("extra" in the JSON line)
+EXTRA_WORKLOADS = [("maskgit-text-24L-d768-T8", "bf16", 3), ("maskgit-text-24L-d768-T12", "bf16", 3), ("vit-s-recon", "bf16", 5),
+                   ("maskgit-text-24L-d1024-512px-T18", "bf16", 2), (DEFAULT_WORKLOAD, "fp32", 2)]
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# rank launcher: `python bench.py --gpus N` with no WORLD_SIZE starts N fresh child processes (one per GPU) and
+# relays rank 0's JSON line.  Decided before anything in this process touches the GPU; the parent never does.
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    port = str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    text, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in text.decode(errors="replace").splitlines() if ln.strip().startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    rc = max(abs(c) for c in codes)
+    if rc == 0 and not lines:
+        rc = 1
+    return rc
 
 
 # ---------------------------------------------------------------------------------------------
 # algorithmic work (2*M*N*K per GEMM, 4*N*Nkv*inner per attention core)
 # ---------------------------------------------------------------------------------------------
 def layer_flops(D, heads, mlp_dim, N, stage2, ctx_len):
+    from paintmind_amd.ops import swiglu_hidden
     inner, hf = heads * 64, swiglu_hidden(mlp_dim)
     proj_self = 4 * 2 * N * D * inner
     core_self = 4 * N * N * inner
@@ -69,13 +110,13 @@ def layer_flops(D, heads, mlp_dim, N, stage2, ctx_len):
     return gemm, attn
 
 
-def vit_flops(tower, embed_dim, patch_k, encode):
+def vit_flops(tower, embed_dim, patch_k, encode, n_embed=8192):
     N = (tower["image_size"] // tower["patch_size"]) ** 2
     g, a = layer_flops(tower["dim"], tower["num_head"], tower["mlp_dim"], N, False, None)
     gemm, attn = g * tower["depth"], a * tower["depth"]
     gemm += 2 * N * patch_k * tower["dim"] + 2 * N * tower["dim"] * embed_dim
     if encode:
-        gemm += 2 * N * embed_dim * 8192          # the VQ distance product (quantize.py:26)
+        gemm += 2 * N * embed_dim * n_embed       # the VQ distance product (quantize.py:26)
     return gemm, attn
 
 
@@ -86,20 +127,56 @@ def s2_step_flops(cfg, N, embed_dim, n_embed, ctx_len):
     return gemm, attn
 
 
+def stage1_cfg(cfg_name):
+    from paintmind_amd.config import ver2cfg
+    return ver2cfg["vit-s-vqgan"] if cfg_name is None else ver2cfg[ver2cfg[cfg_name]["stage1"]]
+
+
+def work_per_step(workload, decode_every_step=True):
+    """(gemm flops, attention flops, sampled logits bytes) of one bench step on one GPU"""
+    from paintmind_amd.config import ver2cfg
+    cfg_name, B, T, L = WORKLOADS[workload]
+    vq = stage1_cfg(cfg_name)
+    pk = 3 * vq["enc"]["patch_size"] ** 2
+    if cfg_name is None:
+        ge, ae = vit_flops(vq["enc"], vq["embed_dim"], pk, True, vq["n_embed"])
+        gd, ad = vit_flops(vq["dec"], vq["embed_dim"], pk, False)
+        return B * (ge + gd), B * (ae + ad), 0
+    cfg = ver2cfg[cfg_name]
+    N = (vq["enc"]["image_size"] // vq["enc"]["patch_size"]) ** 2
+    gs, as_ = s2_step_flops(cfg, N, vq["embed_dim"], vq["n_embed"], L)
+    gd, ad = vit_flops(vq["dec"], vq["embed_dim"], pk, False)
+    n_dec = T if decode_every_step else 1
+    return B * (T * gs + n_dec * gd), B * (T * as_ + n_dec * ad), B * T * N * vq["n_embed"] * 4
+
+
 # ---------------------------------------------------------------------------------------------
 def build(workload, device, dtype):
-    cfg_name, B, T, L = WORKLOADS[workload]
+    import torch
+    import paintmind_amd as pm
+    from paintmind_amd.config import ver2cfg
+    from paintmind_amd.generate import Pipeline
+    cfg_name = WORKLOADS[workload][0]
     torch.manual_seed(0)
     if cfg_name is None:
         model = pm.create_model(arch="vqgan", version="vit-s-vqgan", pretrained=False).to(device).eval()
         model.set_compute_dtype(dtype)
-        return model, None
+        return model
     pipe = Pipeline(pm.Config(ver2cfg[cfg_name]), stage1_pretrained=False).to(device).eval()
     pipe.set_compute_dtype(dtype)
-    return pipe, ver2cfg[cfg_name]
+    return pipe
+
+
+def lanes_arg(streams=None):
+    s = STREAMS if streams is None else streams
+    if LANE_SPLIT and s > 1:
+        return tuple(int(x) for x in LANE_SPLIT.split(","))
+    return s
 
 
 def make_step(workload, model, device, rank, decode_every_step=True):
+    import torch
+    from paintmind_amd.config import ver2cfg
     cfg_name, B, T, L = WORKLOADS[workload]
     if cfg_name is None:
         x = (torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(rank)) * 2 - 1).to(device)
@@ -107,6 +184,7 @@ def make_step(workload, model, device, rank, decode_every_step=True):
         def step(i):
             z, _, _ = model.encode(x)
             return model.decode(z)
+        step.inputs = x
         return step
     pipe = model
     ctx = None
@@ -116,40 +194,89 @@ def make_step(workload, model, device, rank, decode_every_step=True):
     flags = [True] * T if decode_every_step else [t == T - 1 for t in range(T)]
 
     def step(i, join=True, streams=None):
-        STREAMS = globals()["STREAMS"] if streams is None else streams
-        lanes = STREAMS
-        if LANE_SPLIT and STREAMS > 1:
-            lanes = tuple(int(x) for x in LANE_SPLIT.split(","))
+        s = STREAMS if streams is None else streams
         # join=False (single-GPU timed loop): the micro-batch lanes are not joined between steps, so consecutive
         # steps pipeline across lanes; the caller joins once before the closing synchronize
-        if STREAMS > 1 and not join:
+        if s > 1 and not join:
             return pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=1000 + i, image_base=rank * B, use_graph=USE_GRAPH,
-                                     streams=lanes, join=False, wait_current=False)
+                                     streams=lanes_arg(s), join=False, wait_current=False)
         ids, imgs = pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=1000 + i, image_base=rank * B, use_graph=USE_GRAPH,
-                                      streams=lanes, wait_current=False)
+                                      streams=lanes_arg(s), wait_current=False)
         return imgs[-1]
     step.joins = True
+    step.ctx, step.flags = ctx, flags
     return step
 
 
-def work_per_step(workload):
-    """(gemm flops, attention flops, sampled logits bytes) of one bench step on one GPU"""
+def self_check(workload, model, step, device, rank):
+    """The timed configuration (compute dtype as built, hipGraph replay, concurrent lanes) against the eager single-stream
+    loop on the same seed: ids and every decoded image bit-identical (reference generate.py:183-198 has ONE code path).
+    Runs after the setup calls (graphs captured), outside the timed region.  Returns (ok, detail)."""
+    import torch
     cfg_name, B, T, L = WORKLOADS[workload]
-    vq = ver2cfg["vit-s-vqgan"]
-    pk = 3 * vq["enc"]["patch_size"] ** 2
     if cfg_name is None:
-        ge, ae = vit_flops(vq["enc"], vq["embed_dim"], pk, True)
-        gd, ad = vit_flops(vq["dec"], vq["embed_dim"], pk, False)
-        return B * (ge + gd), B * (ae + ad), 0
-    cfg = ver2cfg[cfg_name]
-    gs, as_ = s2_step_flops(cfg, 1024, vq["embed_dim"], vq["n_embed"], L)
-    gd, ad = vit_flops(vq["dec"], vq["embed_dim"], pk, False)
-    return B * T * (gs + gd), B * T * (as_ + ad), B * T * 1024 * vq["n_embed"] * 4
+        x = step.inputs
+        z, _, idx = model.encode(x)
+        rec, rec2 = model.decode(z), model.decode_from_indice(idx)
+        z1, _, idx1 = model.encode(x[:2].contiguous())
+        ok = bool(torch.isfinite(rec).all()) and float(rec.abs().max()) <= 1.0 and torch.equal(idx[:2], idx1) \
+            and float((rec - rec2).abs().max()) < 2e-2
+        return ok, "encode/decode finite, clamped, batch-invariant tokens, decode(z) == decode_from_indice(idx)"
+    seed = 424242
+    kw = dict(seed=seed, image_base=rank * B)
+    ids_t, imgs_t = model.generate_ids(step.ctx, B, T, 1.0, 5, step.flags, use_graph=USE_GRAPH, streams=lanes_arg(), **kw)
+    ids_e, imgs_e = model.generate_ids(step.ctx, B, T, 1.0, 5, step.flags, use_graph=False, streams=1, **kw)
+    torch.cuda.synchronize(device)
+    ok = torch.equal(ids_t, ids_e) and torch.equal(imgs_t, imgs_e) and bool(torch.isfinite(imgs_e).all()) \
+        and int((ids_e == model.mask_token_id).sum(1).max()) == 1 and int((ids_e == model.mask_token_id).sum(1).min()) == 1
+    return ok, (f"hipGraph={USE_GRAPH} lanes={lanes_arg()} ids+images bit-identical to the eager single-stream loop, "
+                f"one residual mask token per image")
+
+
+def time_steps(step, device, n_setup, n_warm, n_timed, free_running):
+    import torch
+    for i in range(n_setup):
+        step(-1 - i)
+    torch.cuda.synchronize(device)
+    for i in range(n_warm):
+        step(i)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(n_timed):
+        if free_running:
+            step(n_warm + i, join=False)
+        else:
+            step(n_warm + i)
+    torch.cuda.synchronize(device)
+    return (time.perf_counter() - t0) / n_timed
+
+
+def extra_workload(name, dtype_name, steps, device):
+    """one more workload under the same harness (setup 2 = sizing + graph capture, 1 warm-up, `steps` timed)"""
+    import torch
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    model = build(name, device, dtype)
+    step = make_step(name, model, device, 0)
+    pipeline = WORKLOADS[name][0] is not None
+    ok = True
+    dt = time_steps(step, device, 2, 1, steps, pipeline and STREAMS > 1)
+    if pipeline:
+        ok, _ = self_check(name, model, step, device, 0)
+    B, T = WORKLOADS[name][1], WORKLOADS[name][2]
+    gf, af, _ = work_per_step(name)
+    out = {"images_per_s": round(B / dt, 2), "ms_per_step": round(dt * 1e3, 3), "batch": B, "timesteps": T, "steps": steps,
+           "dtype": dtype_name, "tflops": round((gf + af) / dt / 1e12, 1)}
+    if pipeline:
+        out["self_check"] = "ok" if ok else "FAILED"
+    del step, model
+    torch.cuda.empty_cache()
+    return out
 
 
 def usable_cores():
     """threads this process may actually run on: affinity mask, capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    limited = False
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
             txt = open(path).read().split()
@@ -158,68 +285,127 @@ def usable_cores():
             else:
                 quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
             if quota not in ("max", "-1"):
-                n = min(n, max(1, int(float(quota) / period)))
+                q = max(1, int(float(quota) / period))
+                if q < n:
+                    n, limited = q, True
         except Exception:
             pass
-    return max(1, min(n, 64))
-
-
-def log(msg):
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+    return max(1, min(n, 64)), limited
 
 
 def cpu_baseline(workload):
     """oracle/torch_port.py -- a functional port of the reference's torch-CPU path -- timed on this host's
-    cores on a bounded sample of the same workload (fp32, B=1)."""
+    cores on a bounded sample of the same workload (fp32): B=1 best of 3, and B=8 on two of the T steps."""
+    import torch
+    import paintmind_amd as pm
     from oracle import torch_port as TP
+    from paintmind_amd.config import ver2cfg
+    from paintmind_amd.generate import Pipeline
     cfg_name, B, T, L = WORKLOADS[workload]
-    cores = usable_cores()
+    cores, limited = usable_cores()
     torch.set_num_threads(cores)
-    log(f"cpu_baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
+    host = os.cpu_count()
+    cores_note = (f"{cores} threads = this container's cgroup CPU quota; the host has {host} logical cores"
+                  if limited else f"{cores} threads (affinity mask; host has {host} logical cores)")
+    log(f"cpu_baseline on {cores_note}")
     torch.manual_seed(0)
-    vq = ver2cfg["vit-s-vqgan"]
+    vq = stage1_cfg(cfg_name)
+    base = {"unit": "images/s", "cores": cores, "cores_note": cores_note, "host_cores": host, "kind": "port"}
     with torch.no_grad():
         if cfg_name is None:
             m = pm.create_model(arch="vqgan", version="vit-s-vqgan", pretrained=False)
             p = {k: v.detach() for k, v in m.state_dict().items()}
             x = torch.rand(1, 3, 256, 256) * 2 - 1
             TP.vqgan_decode(TP.vqgan_encode(x, p, vq)[0], p, vq)            # warm-up
-            reps = 10
+            best = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    TP.vqgan_decode(TP.vqgan_encode(x, p, vq)[0], p, vq)
+                best = min(best, (time.perf_counter() - t0) / 4)
+            x8 = torch.rand(8, 3, 256, 256) * 2 - 1
             t0 = time.perf_counter()
-            for _ in range(reps):
-                TP.vqgan_decode(TP.vqgan_encode(x, p, vq)[0], p, vq)
-            dt = (time.perf_counter() - t0) / reps
-            return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-                    "sample": f"{reps} x (encode+decode) of one 256x256 image, torch-CPU fp32 port of the reference, B=1"}
+            TP.vqgan_decode(TP.vqgan_encode(x8, p, vq)[0], p, vq)
+            b8 = 8 / (time.perf_counter() - t0)
+            return dict(base, value=round(1.0 / best, 4), value_b8=round(b8, 4),
+                        sample="best of 3 x (4 x encode+decode of one 256x256 image), torch-CPU fp32 port of the reference, B=1; "
+                               "value_b8: one encode+decode at B=8")
         pipe = Pipeline(pm.Config(ver2cfg[cfg_name]), stage1_pretrained=False)
         p = {k: v.detach() for k, v in pipe.state_dict().items() if not k.startswith("text_model")}
-        ids = torch.full((1, 1024), vq["n_embed"], dtype=torch.long)
-        ctx = None if L is None else torch.randn(1, L, ver2cfg[cfg_name]["context_dim"])
-        TP.sample_step(ids, 0.9, ctx, 5, 1.0, torch.rand(1, 1024, vq["n_embed"]), p, vq, ver2cfg[cfg_name])   # warm-up
-        t0 = time.perf_counter()
-        for step in range(T):
-            noise = torch.rand(1, 1024, vq["n_embed"])
-            ids, _, _ = TP.sample_step(ids, TP.mask_schedule((step + 1) / T), ctx, 5, 1.0 * (1 - step / T), noise, p, vq,
-                                       ver2cfg[cfg_name])
-        dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"one full {T}-step generate of ONE image (B=1, every step with its ViT decode), torch-CPU fp32 port "
-                      f"of the reference on {cores} threads"}
+        N = pipe.num_tokens
+
+        def run(Bc, steps):
+            ids = torch.full((Bc, N), vq["n_embed"], dtype=torch.long)
+            ctx = None if L is None else torch.randn(Bc, L, ver2cfg[cfg_name]["context_dim"])
+            t0 = time.perf_counter()
+            for step in steps:
+                noise = torch.rand(Bc, N, vq["n_embed"])
+                ids, _, _ = TP.sample_step(ids, TP.mask_schedule((step + 1) / T), ctx, 5, 1.0 * (1 - step / T), noise, p, vq,
+                                           ver2cfg[cfg_name])
+            return time.perf_counter() - t0
+        run(1, [0])                                                         # warm-up
+        best = min(run(1, range(T)) for _ in range(3))
+        t8 = run(8, [0, 1])                                                 # every step is a full forward + decode: same cost
+    return dict(base, value=round(1.0 / best, 4), value_b8=round(8.0 / (t8 * T / 2), 4),
+                sample=f"best of 3 full {T}-step generates of ONE image (B=1, every step with its ViT decode), torch-CPU fp32 port "
+                       f"of the reference; value_b8: B=8 timed on 2 of the {T} steps (all steps cost the same) and scaled to {T}")
 
 
 def pmc_traffic(workload, dtype):
-    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and
+    """HBM bytes per GEMM launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc runs of this same command, read side doubled per the gfx950 correction).
     Only valid for the configuration it was collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if workload != "maskgit-uncond-12L-d512-T8" or dtype != "bf16" or not os.path.exists(path):
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if workload != DEFAULT_WORKLOAD or dtype != "bf16" or not paths:
         return None
     try:
-        fam = json.load(open(path))["families"]["gemm"]
+        fam = json.load(open(paths[-1]))["families"]["gemm"]
         return {"hbm_bytes_per_launch": round(fam["hbm_bytes_per_launch"]), "read": round(fam["hbm_read_bytes_per_launch"]),
-                "write": round(fam["hbm_write_bytes_per_launch"]), "source": "profiles/r01_pmc_traffic.json"}
+                "write": round(fam["hbm_write_bytes_per_launch"]), "source": os.path.relpath(paths[-1], ROOT)}
     except Exception:
         return None
+
+
+def flush_c_stdout():
+    # RCCL writes its version banner to the C stdout buffer; push that out first so the JSON line is the last line
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def run_launch_selftest(args, rank, world):
+    """no GPU, no compute: N gloo ranks, the shard / gather / max-over-ranks / JSON plumbing of the real run"""
+    import torch
+    import torch.distributed as dist
+    from paintmind_amd.dist import gather_images
+    if rank != 0:
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = WORKLOADS["launch-selftest"][1]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        local = torch.full((B, 3, 4, 4), float(rank))
+        got = gather_images(local, [B] * world) if world > 1 else local
+        if rank == 0:
+            assert got.shape[0] == B * world and all(float(got[r * B, 0, 0, 0]) == r for r in range(world))
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [float(x) for x in allt]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "launch-selftest", "value": round(world * B * args.steps / max(per_rank), 3), "unit": "images/s",
+                          "n_gpus": world, "ranks": world, "steps": args.steps, "warmup": args.warmup,
+                          "per_rank_images_per_s": [round(B * args.steps / e, 3) for e in per_rank], "data": "none (launcher self-test)"}),
+              flush=True)
+    return 0
 
 
 def main():
@@ -227,18 +413,28 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="maskgit-uncond-12L-d512-T8", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--final-decode-only", action="store_true", help="decode only the last step's image (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads measured after the headline")
     args = ap.parse_args()
+
+    force_dist = os.environ.get("PM_BENCH_FORCE_DIST") == "1"
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist):
+        return launch_ranks(args.gpus)              # this process never touches the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a {args.gpus}-rank launch (torch.distributed.run), WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.workload == "launch-selftest":
+        return run_launch_selftest(args, rank, world)
+
+    import torch
+    from paintmind_amd import ops
     if rank != 0:
         # only rank 0 reports; the other ranks' stdout would only carry library banners (RCCL prints its version
         # there) that could land after rank 0's JSON line
@@ -246,14 +442,14 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = None
-    if world > 1 or os.environ.get("PM_BENCH_FORCE_DIST") == "1":      # the env switch exercises the RCCL path on one GPU
+    if world > 1 or force_dist:                       # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     log(f"building {args.workload} ({args.dtype}) on rank {rank}/{world}")
-    model, _ = build(args.workload, device, dtype)
+    model = build(args.workload, device, dtype)
     step = make_step(args.workload, model, device, rank, decode_every_step=not args.final_decode_only)
     B = WORKLOADS[args.workload][1]
 
@@ -285,6 +481,22 @@ def main():
     for i in range(2):
         step(-1 - i)
     torch.cuda.synchronize(device)
+    log("self-check of the timed configuration against the eager single-stream loop")
+    ok, detail = self_check(args.workload, model, step, device, rank)
+    if dist is not None:
+        flag = torch.tensor([1 if ok else 0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if not ok:
+        log("SELF-CHECK FAILED: " + detail)
+        if dist is not None:
+            dist.destroy_process_group()
+        flush_c_stdout()
+        if rank == 0:
+            print(json.dumps({"metric": "256x256 images/sec, 8-step MaskGIT decode (vit-s-vqgan), whole job", "value": None,
+                              "self_check": "FAILED: timed configuration differs from the eager single-stream loop", "n_gpus": world}),
+                  flush=True)
+        return 1
     log("warm-up")
     free_running = getattr(step, "joins", False) and STREAMS > 1
     for i in range(args.warmup):
@@ -305,13 +517,19 @@ def main():
         else:
             gather(step(args.warmup + i))
     torch.cuda.synchronize(device)
+    own_elapsed = time.perf_counter() - t0              # this rank's own K steps (before waiting for the slowest rank)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = [own_elapsed]
     if dist is not None:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        mine = torch.tensor([own_elapsed], device=device, dtype=torch.float64)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank = [float(x.item()) for x in allt]
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
@@ -325,24 +543,22 @@ def main():
                    "parallelism": f"dp{world} (independent images, no data-path collective)",
                    "hip_graph": bool(USE_GRAPH), "concurrent_micro_batches": STREAMS},
         "images_per_s_per_gpu": round(value / world, 3),
+        "self_check": "ok", "self_check_detail": detail,
+        "rccl_ranks": dist.get_world_size() if dist is not None else 0,
+        "per_rank_images_per_s": [round(B * args.steps / e, 3) for e in per_rank],
     }
 
     log(f"timed region done: {ms_per_step:.1f} ms/step")
+    pipeline = WORKLOADS[args.workload][0] is not None
     if rank == 0 and not args.no_roofline:
         # per-family kernel time of ONE more step, bracketed by hipEvents on the launch stream
-        gf, af, sample_bytes = work_per_step(args.workload)
-        if args.final_decode_only and WORKLOADS[args.workload][0] is not None:
-            T = WORKLOADS[args.workload][2]
-            vq = ver2cfg["vit-s-vqgan"]
-            gd, ad = vit_flops(vq["dec"], vq["embed_dim"], 192, False)
-            gf -= B * (T - 1) * gd
-            af -= B * (T - 1) * ad
+        gf, af, sample_bytes = work_per_step(args.workload, decode_every_step=not args.final_decode_only)
         ops.timing_reset()
         ops.timing_enable(True)
-        if WORKLOADS[args.workload][0] is None:
-            step(10_000)
-        else:
+        if pipeline:
             step(10_000, streams=1)                    # timing on => one stream, eager loop, every launch bracketed
+        else:
+            step(10_000)
         torch.cuda.synchronize(device)
         ops.timing_enable(False)
         fam = {f: ops.timing_get(f) for f in ("gemm", "attention", "layernorm", "sample", "vq", "rowops")}
@@ -360,34 +576,38 @@ def main():
             f: {"launches": fam[f][0], "ms": round(fam[f][1], 3)} for f in fam}
         if ms_a > 0:
             result["kernel_families"]["attention"]["tflops"] = round(af / (ms_a * 1e-3) / 1e12, 2)
+            result["kernel_families"]["attention"]["frac_of_bf16_peak"] = round(af / (ms_a * 1e-3) / 1e12 / peak, 4)
         if ms_s > 0 and sample_bytes:
             result["kernel_families"]["sample"]["logits_GBps"] = round(sample_bytes / (ms_s * 1e-3) / 1e9, 1)
         result["end_to_end_tflops_per_gpu"] = round((gf + af) / (ms_per_step * 1e-3) / 1e12, 2)
-    if rank == 0 and world == 1 and WORKLOADS[args.workload][0] is not None and not args.final_decode_only:
+    extra = {}
+    if rank == 0 and world == 1 and pipeline and not args.final_decode_only:
         # secondary number (NOT the headline): same loop, but only the image of the last step is decoded
         alt = make_step(args.workload, model, device, rank, decode_every_step=False)
-        for i in range(3):
-            alt(i)
-        torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        for i in range(3):
-            alt(3 + i, join=False) if STREAMS > 1 else alt(3 + i)
-        torch.cuda.synchronize(device)
-        result["extra"] = {"final_decode_only_images_per_s": round(3 * B / (time.perf_counter() - t1), 2)}
+        dt = time_steps(alt, device, 2, 1, 3, STREAMS > 1)
+        extra["final_decode_only_images_per_s"] = round(B / dt, 2)
+    if rank == 0 and world == 1 and not args.no_extra and args.workload == DEFAULT_WORKLOAD and args.dtype == "bf16":
+        del step, model
+        torch.cuda.empty_cache()
+        for name, dt_name, k in EXTRA_WORKLOADS:
+            key = name if dt_name == "bf16" else f"{name}-{dt_name}-verify"
+            log(f"extra workload {key}")
+            try:
+                extra[key] = extra_workload(name, dt_name, k, device)
+            except Exception as e:                      # an extra never takes the headline down
+                extra[key] = {"error": f"{type(e).__name__}: {e}"}
+    if extra:
+        result["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    # RCCL writes its version banner to the C stdout buffer; push that out first so the JSON line is the last line
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
+    flush_c_stdout()
     if rank == 0:
         print(json.dumps(result), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,0 +1,37 @@
+"""bench.py --gpus N must start its own N ranks when no launcher wrapped it (decided before any GPU call), relay rank
+0's JSON line and carry the per-rank figures.  Exercised on CPU with the compute-free `launch-selftest` workload
+(gloo group, the same shard/gather plumbing as the real run)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "launch-selftest", "--steps", "3", *extra],
+                       capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks():
+    out = _run("--gpus", "2")
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and len(out["per_rank_images_per_s"]) == 2 and out["value"] > 0
+
+
+def test_single_rank_runs_in_process_and_forced_dist_spawns_one_child():
+    assert _run("--gpus", "1")["n_gpus"] == 1
+    assert _run("--gpus", "1", env={"PM_BENCH_FORCE_DIST": "1"})["n_gpus"] == 1
+
+
+def test_mismatched_world_size_is_an_error():
+    e = dict(os.environ, WORLD_SIZE="3", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "launch-selftest", "--gpus", "2"],
+                       capture_output=True, text=True, timeout=120, env=e)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
