@@ -151,6 +151,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Wave-wide butterfly reductions on the VALU only (DPP within a row of 16 lanes, then the gfx950 row / half swaps):
+// no ds_bpermute, so nothing goes through the LDS pipe and no lgkmcnt wait sits between the steps.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float swap16(float v) {   // value of lane ^ 16
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((threadIdx.x & 16) ? a[1] : a[0]);
+}
+#ifdef PM_WAVE_REDUCE_BPERMUTE
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -161,6 +171,36 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+#else
+// quad_perm [1,0,3,2] = 0xB1 (lane^1), quad_perm [2,3,0,1] = 0x4E (lane^2), row_half_mirror = 0x141 (the other quad of
+// the 8-lane half row once the quads are uniform), row_mirror = 0x140 (the other half row); then rows and halves
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    {
+        auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+        auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    {
+        auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+        auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    }
+    return v;
+}
+#endif
 
 // max without the canonicalising `v_max x,x,x` hipcc puts in front of fmaxf() on MFMA results
 __device__ __forceinline__ float vmax2(float a, float b) {

@@ -21,10 +21,11 @@ from util import load_golden
 
 pytestmark = pytest.mark.gpu
 
-# measured on MI355X (round 2): max |bf16 - fp32| logit 0.0xx at logits std 0.32; asserted with ~2x head-room
-BF16_LOGIT_MAXERR = 0.05
-BF16_LOGIT_MEANERR = 0.006
-BF16_ROW_COSINE = 0.999
+# measured on MI355X (round 2): max |bf16 - fp32| logit 0.0112, mean 0.00195, min row cosine 0.99997, top-1 agreement 0.990
+# (logits std 0.32, median top-2 gap 0.025); asserted with ~2x head-room
+BF16_LOGIT_MAXERR = 0.025
+BF16_LOGIT_MEANERR = 0.004
+BF16_ROW_COSINE = 0.9999
 
 
 @pytest.fixture(scope="module")
@@ -57,7 +58,7 @@ def test_bf16_one_step_against_fp32_verify_full_size(pipe512):
           f"row cosine min {float(cos.min()):.6f} top-1 agreement {agree:.4f} "
           f"img mean abs dev {float((img16 - img32).abs().mean()):.5f} ids agreement {float((ids16 == ids32).float().mean()):.4f}")
     assert float(err.max()) < BF16_LOGIT_MAXERR and float(err.mean()) < BF16_LOGIT_MEANERR
-    assert float(cos.min()) > BF16_ROW_COSINE
+    assert float(cos.min()) > BF16_ROW_COSINE and agree >= 0.98
     # a flip needs the two candidates closer than the two errors combined
     assert bool((gap[flips] < 2 * BF16_LOGIT_MAXERR).all())
     # and with this error level at most the rows whose gap is inside the noise may flip
@@ -91,3 +92,28 @@ def test_timed_path_graph_and_lanes_bit_identical_to_eager(name, B, L, pipe512):
             assert torch.equal(imgs, eager[seed][1]), (name, seed)
     finally:
         pipe.set_compute_dtype(torch.float32)
+
+
+def test_concurrent_lanes_are_deterministic_at_dim_1024():
+    """Three lanes running the stage-2 forward concurrently must reproduce their sequential results bit for bit.
+    dim 1024 / 16 heads is the shape whose LayerNorm lost rows (1 % of forwards) before the wave reductions moved from
+    ds_bpermute to DPP: tools/lane_race_stress.py.  600 concurrent forwards here."""
+    cfg = dict(ver2cfg["bench-text-24L-d768"], dim=1024, num_head=16, mlp_dim=4096, depth=2, context_dim=1024)
+    torch.manual_seed(0)
+    pipe = Pipeline(pm.Config(cfg), stage1_pretrained=False).to(dev()).eval()
+    pipe.set_compute_dtype(torch.bfloat16)
+    lanes = pipe._lanes(3)
+    g = torch.Generator().manual_seed(3)
+    toks = [torch.randn(2, 1024, 32, generator=g).to(dev()) for _ in range(3)]
+    torch.cuda.synchronize()
+    ref = [lanes[i][0].forward(toks[i], None).clone() for i in range(3)]
+    torch.cuda.synchronize()
+    bad = 0
+    for rep in range(200):
+        res = []
+        for i, (e, v, st) in enumerate(lanes):
+            with torch.cuda.stream(st):
+                res.append(e.forward(toks[i], None))
+        torch.cuda.synchronize()
+        bad += sum(int(not torch.equal(a, b)) for a, b in zip(res, ref))
+    assert bad == 0, f"{bad} / 600 concurrent forwards differ from the sequential result"
