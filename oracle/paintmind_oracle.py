@@ -277,6 +277,41 @@ def sample_step(ids, mask_ratio, context, topk, temperature, noise, p, cfg, s2cf
     return new_ids, img, aux
 
 
+def region_keep_mask(coord, image_size, patch_size, keep_inside):
+    """generate.py:204-208 (inpaint: ones with the rectangle zeroed) / :223-227 (outpaint: zeros with the rectangle
+    set).  coord = (x, y, h, w) in pixels, floor-divided by the patch size; note the reference slices rows with
+    y:y+h and columns with x:x+w.  -> bool [1, grid*grid], True = token is kept."""
+    s = patch_size
+    x, y, h, w = coord[0] // s, coord[1] // s, coord[2] // s, coord[3] // s
+    g = image_size // s
+    keep = np.zeros((g, g), dtype=bool) if keep_inside else np.ones((g, g), dtype=bool)
+    keep[y:y + h, x:x + w] = keep_inside
+    return keep.reshape(1, -1)
+
+
+def region_loop(img, coord, context, timesteps, topk, temperature, p, cfg, s2cfg, keep_inside, noises=None, ids=None):
+    """Pipeline.inpaint (keep_inside=False, generate.py:200-217) / Pipeline.outpaint (True, :219-236):
+    encode -> ids kept outside / inside the rectangle, mask id elsewhere -> `timesteps` sample steps -> last image.
+
+    The reference computes `ids * mask + mask_token_id * (1 - mask)` in float (:210,229), which nn.Embedding then
+    rejects (tests/golden/api.json: inpaint_runs == false); this is that expression with the evident integer result.
+    `noises`: one uniform(0,1) array [B,N,V] per step (irrelevant for topk=1); `ids`: start from given token ids
+    instead of encoding (used to compare the composition on identical tokens).  -> (img, ids, aux of the last step)"""
+    vq_p = {k[len("vqgan."):]: v for k, v in p.items() if k.startswith("vqgan.")}
+    if ids is None:
+        _, _, ids = vqgan_encode(img, vq_p, cfg)                                            # to_latent, :125-131
+    e = cfg["enc"]
+    keep = region_keep_mask(coord, e["image_size"], e["patch_size"], keep_inside)
+    ids = np.where(keep, ids, cfg["n_embed"]).astype(np.int64)
+    out, aux = None, None
+    for step in range(timesteps):
+        r = mask_schedule((step + 1) / timesteps)
+        cur_temp = temperature * (1 - step / timesteps)
+        noise = noises[step] if noises is not None else np.full(ids.shape + (cfg["n_embed"],), 0.5, dtype=F)
+        ids, out, aux = sample_step(ids, r, context, topk, cur_temp, noise, p, cfg, s2cfg)
+    return out, ids, aux
+
+
 # ------------------------------------------------------------------------------------------------
 # masked-token objective, forward only (generate.py:78-146)
 # ------------------------------------------------------------------------------------------------

@@ -268,7 +268,7 @@ class Pipeline(nn.Module):
         out = [] if imgs is None else [im if keep_on_device else im.cpu() for im in imgs]
         return (out, ids) if return_ids else out
 
-    def _region_loop(self, img, coord, text, timesteps, topk, temperature, keep_inside, seed=None):
+    def _region_loop(self, img, coord, text, timesteps, topk, temperature, keep_inside, seed=None, return_ids=False):
         if seed is None:
             seed = _draw_seed()                 # one stream per call; the step index separates the steps
         z, ids, text = self.to_latent(img, text)
@@ -288,14 +288,16 @@ class Pipeline(nn.Module):
             masked_r = mask_schedule(progress)
             cur_temp = temperature * (1 - step / timesteps)
             ids, out = self.sample(ids, mask_ratio=masked_r, text=text, topk=topk, temperature=cur_temp, seed=seed, step=step)
-        return out
+        return (out, ids) if return_ids else out
 
     @torch.no_grad()
-    def inpaint(self, img, coord, text=None, timesteps=1, topk=1, temperature=0, seed=None):
+    def inpaint(self, img, coord, text=None, timesteps=1, topk=1, temperature=0, seed=None, return_ids=False):
         """re-generate the rectangle coord=(x,y,h,w) in pixels (generate.py:200-217)."""
-        return self._region_loop(img, coord, text, timesteps, topk, temperature, keep_inside=False, seed=seed)
+        return self._region_loop(img, coord, text, timesteps, topk, temperature, keep_inside=False, seed=seed,
+                                 return_ids=return_ids)
 
     @torch.no_grad()
-    def outpaint(self, img, coord, text=None, timesteps=1, topk=1, temperature=0, seed=None):
+    def outpaint(self, img, coord, text=None, timesteps=1, topk=1, temperature=0, seed=None, return_ids=False):
         """keep the rectangle, re-generate everything else (generate.py:219-236)."""
-        return self._region_loop(img, coord, text, timesteps, topk, temperature, keep_inside=True, seed=seed)
+        return self._region_loop(img, coord, text, timesteps, topk, temperature, keep_inside=True, seed=seed,
+                                 return_ids=return_ids)

@@ -209,8 +209,11 @@ def test_generate_concurrent_micro_batches_match_single_stream(tiny_pipe):
 
 
 def test_reconstruction_figure(tmp_path):
-    """reference reconstruct.py:23-52: file -> transform -> encode -> decode -> 512x256 side-by-side figure"""
+    """reference reconstruct.py:23-52: file -> transform -> encode -> decode -> 512x256 side-by-side figure.
+    Left panel = the transformed input, right panel = restore(decode(encode(x))) checked against the oracle within
+    1 LSB of the 8-bit image (restore truncates, so a 1e-5 float difference may move a pixel by one level)."""
     from PIL import Image
+    from paintmind_amd.reconstruct import restore
     rng = np.random.default_rng(0)
     path = str(tmp_path / "in.png")
     Image.fromarray(rng.integers(0, 256, (300, 300, 3), dtype=np.uint8)).save(path)
@@ -220,18 +223,107 @@ def test_reconstruction_figure(tmp_path):
     left = np.asarray(fig.crop((0, 20, 256, 256)), dtype=np.int32)
     ref = np.asarray(Image.open(path).convert("RGB").resize((320, 320), Image.BICUBIC).crop((32, 32, 288, 288)).crop((0, 20, 256, 256)), dtype=np.int32)
     assert np.abs(left - ref).max() <= 1          # the left half is the (transformed) input
+    # right half: the same weights (seed 0 construction) through the numpy oracle
+    torch.manual_seed(0)
+    m = pm.create_model(arch="vqgan", version="vit-s-vqgan", pretrained=False)
+    p = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    x = pm.stage1_transform(is_train=False, scale=0.8)(Image.open(path).convert("RGB"))[None].numpy()
+    z_o, _, idx_o = O.vqgan_encode(x, p, vq_cfg("vit-s-vqgan"))
+    rec_o = O.vqgan_decode(z_o, p, vq_cfg("vit-s-vqgan"))
+    want = np.asarray(restore(torch.from_numpy(rec_o[0])).crop((0, 20, 256, 256)), dtype=np.int32)
+    right = np.asarray(fig.crop((256, 20, 512, 256)), dtype=np.int32)
+    diff = np.abs(right - want)
+    assert diff.max() <= 1, (int(diff.max()), float((diff > 0).mean()))
 
 
-def test_inpaint_outpaint_run(tiny_pipe):
-    """The reference's inpaint/outpaint crash on float ids (api.json: inpaint_runs == false); this build
-    implements the evident intent.  Unmasked tokens must survive, the image must be finite."""
+def test_checkpoint_round_trip_through_the_factory(tmp_path, vit_s):
+    """factory.py:16-19 + vqmodel.py:43-44: a .pt file holding a reference-layout state_dict, loaded with
+    create_model(pretrained=True, checkpoint_path=...), must reproduce the reference's golden tokens; same for a
+    Pipeline checkpoint (generate.py:75-76) including mask_token and the transformer."""
+    _, d = load_golden("full_vqgan.npz")
+    torch.manual_seed(0)
+    src = pm.create_model(arch="vqgan", version="vit-s-vqgan", pretrained=False)        # == the reference's seed-0 weights (sha-pinned)
+    path = str(tmp_path / "vit-s-vqgan.pt")
+    torch.save(src.state_dict(), path)
+    torch.manual_seed(123)                                                               # different init, then overwritten by the file
+    m = pm.create_model(arch="vqgan", version="vit-s-vqgan", pretrained=True, checkpoint_path=path).to(dev()).eval()
+    x = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(100)) * 2 - 1).to(dev())
+    z, loss, idx = m.encode(x)
+    got, want = n(idx).reshape(-1), d["idx"].reshape(-1).astype(np.int64)
+    mism = got != want
+    assert mism.sum() <= 4 and np.all(d["gap"][mism] < 1e-5)
+    assert torch.equal(idx, vit_s.encode(x)[2])                                          # == the directly constructed model
+    assert maxabs(n(m.decode(t(d["z"])))[:, :, ::4, ::4], d["rec_sub"]) < TOL
+    # Pipeline checkpoint: every non-text key round-trips, and the loaded pipeline samples the same ids
+    torch.manual_seed(1)
+    a = Pipeline(pm.Config(pm.ver2cfg["tiny-pipeline"]), stage1_pretrained=False)
+    ppath = str(tmp_path / "tiny-pipeline.pt")
+    torch.save(a.state_dict(), ppath)
+    pm.ver2cfg["tiny-pipeline-ckpt"] = pm.ver2cfg["tiny-pipeline"]
+    torch.manual_seed(2)
+    b = pm.create_model(arch="pipeline", version="tiny-pipeline-ckpt", pretrained=True, checkpoint_path=ppath)
+    assert all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
+    a, b = a.to(dev()).eval(), b.to(dev()).eval()
+    ia = a.generate(["x", "y"], timesteps=4, topk=3, seed=9, return_ids=True)[1]
+    ib = b.generate(["x", "y"], timesteps=4, topk=3, seed=9, return_ids=True)[1]
+    assert torch.equal(ia, ib)
+    with pytest.raises(ValueError):
+        pm.create_model(arch="nope", version="vit-s-vqgan", pretrained=False)
+
+
+def test_t5_text_tower_feeds_generate_on_the_gpu():
+    """f2: a (randomly initialised) Flan-T5-architecture tower as Pipeline.text_model: follows .to(device), produces
+    (B, 77, ctx) on the GPU and Pipeline.generate consumes it (reference generate.py:58,188)."""
+    from paintmind_amd.modules.encoder import T5TextEmbedder
+    from text_stubs import StubTokenizer, tiny_t5
+    emb = T5TextEmbedder(tokenizer=StubTokenizer(), transformer=tiny_t5(96))
+    torch.manual_seed(4)
+    pipe = Pipeline(pm.Config(pm.ver2cfg["tiny-pipeline"]), stage1_pretrained=False, text_model=emb).to(dev()).eval()
+    ctx = pipe.text_model(["a cat", "a dog"])
+    assert ctx.shape == (2, 77, 96) and ctx.is_cuda
+    imgs, ids = pipe.generate(["a cat", "a dog"], timesteps=4, topk=3, seed=1, return_ids=True)
+    assert len(imgs) == 2 and torch.isfinite(imgs[-1]).all()
+    # the text really conditions the result: the oracle on the same context reproduces the first step
+    p = {k: v.detach().cpu().numpy() for k, v in pipe.state_dict().items() if not k.startswith("text_model")}
+    ids0 = torch.full((2, 16), 64, dtype=torch.long, device=dev())
+    ids1, _ = pipe.sample(ids0, np.float64(0.5), text=ctx, topk=1, temperature=1.0)
+    ids1_o, _, _ = O.sample_step(n(ids0), np.float64(0.5), n(ctx), 1, 1.0, np.full((2, 16, 64), 0.5, np.float32), p,
+                                 pm.ver2cfg["tiny-vqgan"], pm.ver2cfg["tiny-pipeline"])
+    assert np.array_equal(n(ids1), ids1_o)
+
+
+def test_inpaint_outpaint_match_oracle_composition(tiny_pipe):
+    """generate.py:200-236.  The reference itself raises here (float ids into nn.Embedding; api.json: inpaint_runs ==
+    false), so there is no golden: the intended result is the composition encode -> integer keep-mask -> sample loop,
+    restated as O.region_loop, and Pipeline.inpaint / outpaint must reproduce it (ids exact, image 1e-3)."""
     pipe, p, d = tiny_pipe
     assert api_facts()["inpaint_runs"] is False
-    img = t(load_golden("tiny_vqgan.npz")[1]["x"][:1])
-    out = pipe.inpaint(img, (8, 8, 16, 16))
+    vcfg, scfg = pm.ver2cfg["tiny-vqgan"], pm.ver2cfg["tiny-pipeline"]
+    x = load_golden("tiny_vqgan.npz")[1]["x"]
+    ctx = d["context"]
+    text_model = pipe.text_model
+    pipe.text_model = torch.nn.Identity()               # to_latent passes `text` through the text tower (generate.py:129-130)
+    try:
+        for fn, keep_inside in ((pipe.inpaint, False), (pipe.outpaint, True)):
+            for coord, T, use_ctx in (((8, 8, 16, 16), 1, False), ((0, 8, 24, 16), 3, True), ((16, 0, 8, 32), 2, True)):
+                c = ctx if use_ctx else None
+                img, ids = fn(t(x), coord, text=None if c is None else t(c), timesteps=T, return_ids=True)
+                img_o, ids_o, aux = O.region_loop(x, coord, c, T, 1, 0, p, vcfg, scfg, keep_inside)
+                assert np.array_equal(n(ids), ids_o), (fn.__name__, coord, T)
+                assert maxabs(n(img), img_o) < TOL
+                assert img.shape == (3, 3, 32, 32)
+    finally:
+        pipe.text_model = text_model
+    # the default call (reference signature) returns the image only
+    out = pipe.inpaint(t(x[:1]), (8, 8, 16, 16))
     assert out.shape == (1, 3, 32, 32) and torch.isfinite(out).all()
-    out2 = pipe.outpaint(img, (8, 8, 16, 16))
-    assert out2.shape == (1, 3, 32, 32) and torch.isfinite(out2).all()
+    # topk > 1: the Philox stream is drawn per call (torch.manual_seed governs it) and differs between calls
+    torch.manual_seed(5)
+    a = pipe.inpaint(t(x[:1]), (0, 0, 32, 32), timesteps=2, topk=8, temperature=2.0)
+    torch.manual_seed(5)
+    b = pipe.inpaint(t(x[:1]), (0, 0, 32, 32), timesteps=2, topk=8, temperature=2.0)
+    c2 = pipe.inpaint(t(x[:1]), (0, 0, 32, 32), timesteps=2, topk=8, temperature=2.0)
+    assert torch.equal(a, b) and not torch.equal(a, c2)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -316,6 +408,46 @@ def test_full_stage2_against_reference_golden():
     assert maxabs(n(img_g)[:, :, ::4, ::4], d["img1_sub"]) < TOL
     if not bad.any():
         assert maxabs(n(img1)[:, :, ::4, ::4], d["img1_sub"]) < TOL
+
+
+def test_full_size_inpaint_outpaint_against_oracle(vit_s):
+    """vit-s-vqgan + 12L/d512 at B=1: Pipeline.inpaint / outpaint against O.region_loop.  Token ids from the encoder must
+    equal the oracle's except at near-ties of the VQ distance (gap < 1e-5); the loop itself is compared on identical
+    start tokens: predicted ids equal wherever the oracle's top-2 logit gap is >= 1e-4, re-mask decisions equal
+    wherever the score is not within 1e-5 of the cut-off, image of the oracle's predictions within 1e-3."""
+    from paintmind_amd.config import ver2cfg
+    torch.manual_seed(0)
+    pipe = Pipeline(pm.Config(ver2cfg["bench-uncond-12L-d512"]), stage1_pretrained=False).eval()
+    p = {k: v.detach().numpy() for k, v in pipe.state_dict().items() if not k.startswith("text_model")}
+    vq_p = {k[len("vqgan."):]: v for k, v in p.items() if k.startswith("vqgan.")}
+    scfg, vcfg = ver2cfg["bench-uncond-12L-d512"], ver2cfg["vit-s-vqgan"]
+    pipe = pipe.to(dev())
+    x = (torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(7)) * 2 - 1)
+    V = vcfg["n_embed"]
+    _, _, idx_gpu = pipe.vqgan.encode(x.to(dev()))
+    ze = O.vqgan_encode(x.numpy(), vq_p, vcfg, return_pre=True)
+    idx_o = ze[2]
+    mism = n(idx_gpu) != idx_o
+    assert mism.sum() <= 2, int(mism.sum())
+    for fn, keep_inside, coord in ((pipe.inpaint, False, (64, 32, 96, 128)), (pipe.outpaint, True, (64, 32, 96, 128))):
+        img, ids = fn(x.to(dev()), coord, timesteps=1, return_ids=True)
+        img_o, ids_o, aux = O.region_loop(x.numpy(), coord, None, 1, 1, 0, p, vcfg, scfg, keep_inside, ids=n(idx_gpu))
+        keep = O.region_keep_mask(coord, 256, 8, keep_inside)
+        assert int((~keep).sum()) == (12 * 16 if not keep_inside else 1024 - 12 * 16)
+        top2 = -np.sort(-aux["logits"], axis=-1)[..., :2]
+        gap = (top2[..., 0] - top2[..., 1])
+        got = n(ids)
+        m = aux["num_mask"]
+        cutoff = np.sort(aux["score"][0])[-m]
+        near = (gap < 1e-4) | (np.abs(aux["score"] - cutoff) < 1e-5)
+        bad = (got != ids_o) & ~near
+        assert not bad.any(), int(bad.sum())
+        assert (got == V).sum() == (ids_o == V).sum() == m
+        assert np.array_equal(got[keep & (got != V)], n(idx_gpu)[keep & (got != V)])         # kept tokens survive unless re-masked
+        img_pred = pipe.vqgan.decode_from_indice(torch.from_numpy(aux["pred"]).to(dev()))
+        assert maxabs(n(img_pred), img_o) < TOL
+        if np.array_equal(got, ids_o):
+            assert maxabs(n(img), img_o) < TOL
 
 
 def test_bf16_perf_mode_deviation_is_bounded(vit_s):
