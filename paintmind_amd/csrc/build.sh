@@ -1,19 +1,32 @@
 #!/bin/bash
 # Build libpaintmind_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+# An object is rebuilt when the CONTENT of its source, of any header, or the flags changed (sha256 kept beside the object;
+# timestamps are not trusted: a checkout or a copy can make a stale object look newer than its source).  FORCE=1 rebuilds all.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../libpaintmind_hip.so"
 objdir="$here/build"
 mkdir -p "$objdir"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-pids=()
-for f in gemm gemm256 gemm2b attention rowops vq sample loss engine; do
-  src="$here/$f.hip"; obj="$objdir/$f.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$here/common.h" -nt "$obj" ] || [ "$here/gemm_common.h" -nt "$obj" ] || [ "$here/../../include/pmhip.h" -nt "$obj" ]; then
-    hipcc $FLAGS -c "$src" -o "$obj" &
-    pids+=($!)
+units="gemm gemm256 gemm2b attention rowops vq sample loss engine"
+hdrsum="$(cat "$here"/*.h "$here/../../include/pmhip.h" | sha256sum | cut -d' ' -f1)"
+pids=(); built=0; reused=0
+for f in $units; do
+  src="$here/$f.hip"; obj="$objdir/$f.o"; stamp="$objdir/$f.sha"
+  want="$(echo "$FLAGS $hdrsum $(sha256sum < "$src")" | sha256sum | cut -d' ' -f1)"
+  if [ "${FORCE:-0}" != "0" ] || [ ! -f "$obj" ] || [ ! -f "$stamp" ] || [ "$(cat "$stamp")" != "$want" ]; then
+    rm -f "$stamp"
+    ( hipcc $FLAGS -c "$src" -o "$obj" && echo "$want" > "$stamp" ) &
+    pids+=($!); built=$((built + 1))
+  else
+    reused=$((reused + 1))
   fi
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" "$objdir"/{gemm,gemm256,gemm2b,attention,rowops,vq,sample,loss,engine}.o
-echo "built $out"
+rc=0
+for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || rc=1; }; done
+[ $rc -eq 0 ] || { echo "build failed" >&2; exit 1; }
+objs=""; for f in $units; do objs="$objs $objdir/$f.o"; done
+if [ $built -gt 0 ] || [ ! -f "$out" ]; then
+  hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" $objs
+fi
+echo "built $out (compiled $built, reused $reused objects)"
