@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PMHIP_ABI_VERSION 1
+#define PMHIP_ABI_VERSION 2
 
 enum { PMHIP_OK = 0, PMHIP_EINVAL = 1, PMHIP_EHIP = 2, PMHIP_ENOMEM = 3, PMHIP_ESTATE = 4 };
 enum { PMHIP_F32 = 0, PMHIP_BF16 = 1 };
@@ -68,6 +68,37 @@ int pmhip_gemm_swiglu(int dtype, const void* A, int lda, const void* W12p, const
 int pmhip_gemm_heads(int dtype, const void* A, int lda, const void* W, int ldw, int M, int K,
                      int heads, int tokens, int tokens_pad, int nparts, const int* part_kinds_host,
                      void* const* part_outs_host, float q_scale, pmhip_stream stream);
+
+/* ---- LayerNorm folded into the GEMMs either side of it (bf16 mode; stage1/layers.py:54-58, stage2/transformer.py:44-49:
+ * every projection is preceded by a LayerNorm of the residual stream).  y = LN(x) = (x - mean) * rstd * gamma + beta, so
+ *     y . W^T = rstd * (x . (gamma (.) W)^T) - rstd * mean * c + d,   c[n] = sum_k gamma[k] W[n,k],  d[n] = sum_k beta[k] W[n,k].
+ * The GEMM that PRODUCES x (a residual GEMM) also writes x as bf16 and, per row and 64-column chunk, (sum x, sum x^2);
+ * the GEMM that CONSUMES LN(x) multiplies the raw bf16 x by the gamma-scaled weights and applies the formula in its
+ * epilogue.  The separate LayerNorm pass (read 4 B + write 2 B per element) disappears.  Deterministic: no atomics. */
+typedef struct pmhip_lnfold {
+    const float* stats;   /* [M][K/64][2]: per row and 64-column chunk (sum x, sum x^2), written by pmhip_gemm_stats */
+    const float* c;       /* [N]: sum_k of the (rounded) gamma-scaled weight row */
+    const float* d;       /* [N]: sum_k beta[k] * W[n,k] */
+    float eps;            /* LayerNorm eps */
+} pmhip_lnfold;
+
+/* pmhip_gemm with an f32 result that ALSO emits xb_out[M,N] (bf16 copy, row stride ldxb) and stats_out[M][N/64][2].
+ * N must be a multiple of 64. */
+int pmhip_gemm_stats(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
+                     const float* residual, int ldr, int res_rows, float* out, int ldo, void* xb_out,
+                     int ldxb, float* stats_out, int M, int N, int K, pmhip_stream stream);
+/* Consumers: same arguments as pmhip_gemm (no residual) / pmhip_gemm_swiglu / pmhip_gemm_heads, with A = the raw bf16
+ * rows, W = the gamma-scaled weights and `ln` the fold descriptor.  Only shapes served by the 256x256 kernel
+ * (pmhip_lnfold_supported; epi_kind 0 = plain, 1 = SwiGLU, 2 = head split; N counts the packed output rows). */
+int pmhip_gemm_ln(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
+                  int ldo, int out_dtype, int M, int N, int K, const pmhip_lnfold* ln, pmhip_stream stream);
+int pmhip_gemm_swiglu_ln(int dtype, const void* A, int lda, const void* W12p, const float* b12p, void* out,
+                         int ldo, int M, int Hp, int K, const pmhip_lnfold* ln, pmhip_stream stream);
+int pmhip_gemm_heads_ln(int dtype, const void* A, int lda, const void* W, int ldw, int M, int K, int heads,
+                        int tokens, int tokens_pad, int nparts, const int* part_kinds_host,
+                        void* const* part_outs_host, float q_scale, const pmhip_lnfold* ln,
+                        pmhip_stream stream);
+int pmhip_lnfold_supported(int dtype, int epi_kind, int M, int N, int K);
 
 /* softmax(Q K^T) V per (batch, head), no mask, no dropout (modules/attention.py:51-58; the same
  * maths as xformers.ops.memory_efficient_attention at :100).  Q is already scaled.  Layouts as

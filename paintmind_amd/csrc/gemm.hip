@@ -126,6 +126,9 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
     // the LDS stage that is idle after the K loop (stage nk&1: its last reads finished before the final barrier)
     // is the epilogue's transposition buffer
     unsigned char* eraw = lds + (nk & 1) * STAGE_BYTES + wave * EPI_WAVE_BYTES;
+    if constexpr (RPRE) {
+        if (p.xb_out) { wave_epilogue<EPI, OutT, 4, 16, false, -1, true>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre); return; }
+    }
     wave_epilogue<EPI, OutT, 4>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre);
 }
 
@@ -174,9 +177,22 @@ int check_common(const GemmParams& p, int dtype) {
 
 }  // namespace
 
-extern "C" int pmhip_gemm(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
+namespace {
+
+// LayerNorm fold (gemm_common.h): checks shared by the three consumer entry points; fills the consumer fields
+int set_lnfold(GemmParams& p, const pmhip_lnfold* ln, int dtype, int epi, int out_dtype) {
+    if (!ln) return PMHIP_OK;
+    PM_REQUIRE(ln->stats && ln->c && ln->d, "gemm_ln: null fold pointer");
+    PM_REQUIRE(dtype == PMHIP_BF16, "gemm_ln: the LayerNorm fold exists in bf16 mode only");
+    PM_REQUIRE(p.K % 128 == 0, "gemm_ln: K=%d must be a multiple of 128", p.K);
+    p.ln_stats = ln->stats; p.ln_c = ln->c; p.ln_d = ln->d; p.ln_eps = ln->eps; p.ln_nc = p.K / 64;
+    PM_REQUIRE(pm_gemm256_supported(p, dtype, epi, out_dtype), "gemm_ln: shape M=%d N=%d K=%d is not served by the 256x256 kernel", p.M, p.N, p.K);
+    return PMHIP_OK;
+}
+
+int gemm_impl(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
                           const float* residual, int ldr, int res_rows, void* out, int ldo, int out_dtype,
-                          int M, int N, int K, pmhip_stream stream) {
+                          int M, int N, int K, void* xb_out, int ldxb, float* stats_out, const pmhip_lnfold* ln, pmhip_stream stream) {
     GemmParams p{};
     p.A = A; p.W = W; p.bias = bias; p.residual = residual; p.out = out;
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.res_rows = res_rows > 0 ? res_rows : M; p.ldo = ldo;
@@ -188,7 +204,14 @@ extern "C" int pmhip_gemm(int dtype, const void* A, int lda, const void* W, int 
     PM_REQUIRE(!residual || out_dtype == PMHIP_F32, "gemm: a residual needs an f32 output (the residual stream is f32)");
     PM_REQUIRE(out_dtype == PMHIP_F32 || out_dtype == dtype, "gemm: out dtype must be f32 or the compute dtype");
     PM_REQUIRE(out_dtype == PMHIP_F32 || ldo % 8 == 0, "gemm: bf16 output needs ldo to be a multiple of 8");
+    if (xb_out || stats_out) {
+        PM_REQUIRE(xb_out && stats_out && out_dtype == PMHIP_F32 && N % 64 == 0 && ldxb % 4 == 0,
+                   "gemm_stats: needs both outputs, an f32 result and N a multiple of 64");
+        p.xb_out = reinterpret_cast<bf16_t*>(xb_out); p.ldxb = ldxb; p.stats_out = stats_out;
+    }
+    PM_TRY(set_lnfold(p, ln, dtype, EPI_STD, out_dtype));
     hipStream_t s = (hipStream_t)stream;
+    if (ln) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
     if (use2b(p, dtype, EPI_STD, out_dtype)) return pm_gemm2b_launch(p, EPI_STD, out_dtype, s);
     if (use256(p, dtype, EPI_STD, out_dtype)) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_STD, float>(p, s);
@@ -196,8 +219,35 @@ extern "C" int pmhip_gemm(int dtype, const void* A, int lda, const void* W, int 
     return launch<bf16_t, EPI_STD, bf16_t>(p, s);
 }
 
-extern "C" int pmhip_gemm_swiglu(int dtype, const void* A, int lda, const void* W12p, const float* b12p,
-                                 void* out, int ldo, int M, int Hp, int K, pmhip_stream stream) {
+}  // namespace
+
+extern "C" int pmhip_gemm(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
+                          const float* residual, int ldr, int res_rows, void* out, int ldo, int out_dtype,
+                          int M, int N, int K, pmhip_stream stream) {
+    return gemm_impl(dtype, A, lda, W, ldw, bias, residual, ldr, res_rows, out, ldo, out_dtype, M, N, K, nullptr, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int pmhip_gemm_stats(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
+                                const float* residual, int ldr, int res_rows, float* out, int ldo, void* xb_out, int ldxb,
+                                float* stats_out, int M, int N, int K, pmhip_stream stream) {
+    PM_REQUIRE(xb_out && stats_out, "gemm_stats: null output");
+    return gemm_impl(dtype, A, lda, W, ldw, bias, residual, ldr, res_rows, out, ldo, PMHIP_F32, M, N, K, xb_out, ldxb, stats_out, nullptr, stream);
+}
+
+extern "C" int pmhip_gemm_ln(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldo,
+                             int out_dtype, int M, int N, int K, const pmhip_lnfold* ln, pmhip_stream stream) {
+    PM_REQUIRE(ln, "gemm_ln: null fold descriptor");
+    return gemm_impl(dtype, A, lda, W, ldw, bias, nullptr, 0, 0, out, ldo, out_dtype, M, N, K, nullptr, 0, nullptr, ln, stream);
+}
+
+extern "C" int pmhip_lnfold_supported(int dtype, int epi_kind, int M, int N, int K) {
+    GemmParams p{};
+    p.M = M; p.N = N; p.K = K;
+    return dtype == PMHIP_BF16 && K % 128 == 0 && epi_kind >= 0 && epi_kind <= 2 && pm_gemm256_supported(p, dtype, epi_kind, dtype) ? 1 : 0;
+}
+
+static int gemm_swiglu_impl(int dtype, const void* A, int lda, const void* W12p, const float* b12p,
+                                 void* out, int ldo, int M, int Hp, int K, const pmhip_lnfold* ln, pmhip_stream stream) {
     GemmParams p{};
     p.A = A; p.W = W12p; p.bias = b12p; p.out = out;
     p.lda = lda; p.ldw = K; p.ldo = ldo; p.M = M; p.N = 2 * Hp; p.K = K;
@@ -205,16 +255,29 @@ extern "C" int pmhip_gemm_swiglu(int dtype, const void* A, int lda, const void* 
     PM_TRY(check_common(p, dtype));
     PM_REQUIRE(Hp % 64 == 0, "gemm_swiglu: padded hidden width %d must be a multiple of 64", Hp);
     PM_REQUIRE(b12p && out && ldo % 8 == 0, "gemm_swiglu: bias/out required, ldo multiple of 8");
+    PM_TRY(set_lnfold(p, ln, dtype, EPI_SWIGLU, dtype));
     hipStream_t s = (hipStream_t)stream;
+    if (ln) return pm_gemm256_launch(p, EPI_SWIGLU, dtype, s);
     if (use2b(p, dtype, EPI_SWIGLU, dtype)) return pm_gemm2b_launch(p, EPI_SWIGLU, dtype, s);
     if (use256(p, dtype, EPI_SWIGLU, dtype)) return pm_gemm256_launch(p, EPI_SWIGLU, dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_SWIGLU, float>(p, s);
     return launch<bf16_t, EPI_SWIGLU, bf16_t>(p, s);
 }
 
-extern "C" int pmhip_gemm_heads(int dtype, const void* A, int lda, const void* W, int ldw, int M, int K,
+extern "C" int pmhip_gemm_swiglu(int dtype, const void* A, int lda, const void* W12p, const float* b12p,
+                                 void* out, int ldo, int M, int Hp, int K, pmhip_stream stream) {
+    return gemm_swiglu_impl(dtype, A, lda, W12p, b12p, out, ldo, M, Hp, K, nullptr, stream);
+}
+
+extern "C" int pmhip_gemm_swiglu_ln(int dtype, const void* A, int lda, const void* W12p, const float* b12p, void* out, int ldo,
+                                    int M, int Hp, int K, const pmhip_lnfold* ln, pmhip_stream stream) {
+    PM_REQUIRE(ln, "gemm_swiglu_ln: null fold descriptor");
+    return gemm_swiglu_impl(dtype, A, lda, W12p, b12p, out, ldo, M, Hp, K, ln, stream);
+}
+
+static int gemm_heads_impl(int dtype, const void* A, int lda, const void* W, int ldw, int M, int K,
                                 int heads, int tokens, int tokens_pad, int nparts,
-                                const int* part_kinds_host, void* const* part_outs_host, float q_scale,
+                                const int* part_kinds_host, void* const* part_outs_host, float q_scale, const pmhip_lnfold* ln,
                                 pmhip_stream stream) {
     GemmParams p{};
     p.A = A; p.W = W; p.lda = lda; p.ldw = ldw; p.M = M; p.K = K;
@@ -230,9 +293,27 @@ extern "C" int pmhip_gemm_heads(int dtype, const void* A, int lda, const void* W
         PM_REQUIRE(p.kinds[i] >= 0 && p.kinds[i] <= 2, "gemm_heads: bad part kind");
     }
     PM_TRY(check_common(p, dtype));
+    PM_TRY(set_lnfold(p, ln, dtype, EPI_HEADS, dtype));
     hipStream_t s = (hipStream_t)stream;
+    if (ln) return pm_gemm256_launch(p, EPI_HEADS, dtype, s);
     if (use2b(p, dtype, EPI_HEADS, dtype)) return pm_gemm2b_launch(p, EPI_HEADS, dtype, s);
     if (use256(p, dtype, EPI_HEADS, dtype)) return pm_gemm256_launch(p, EPI_HEADS, dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_HEADS, float>(p, s);
     return launch<bf16_t, EPI_HEADS, bf16_t>(p, s);
+}
+
+extern "C" int pmhip_gemm_heads(int dtype, const void* A, int lda, const void* W, int ldw, int M, int K,
+                                int heads, int tokens, int tokens_pad, int nparts,
+                                const int* part_kinds_host, void* const* part_outs_host, float q_scale,
+                                pmhip_stream stream) {
+    return gemm_heads_impl(dtype, A, lda, W, ldw, M, K, heads, tokens, tokens_pad, nparts, part_kinds_host, part_outs_host, q_scale,
+                           nullptr, stream);
+}
+
+extern "C" int pmhip_gemm_heads_ln(int dtype, const void* A, int lda, const void* W, int ldw, int M, int K, int heads,
+                                   int tokens, int tokens_pad, int nparts, const int* part_kinds_host,
+                                   void* const* part_outs_host, float q_scale, const pmhip_lnfold* ln, pmhip_stream stream) {
+    PM_REQUIRE(ln, "gemm_heads_ln: null fold descriptor");
+    return gemm_heads_impl(dtype, A, lda, W, ldw, M, K, heads, tokens, tokens_pad, nparts, part_kinds_host, part_outs_host, q_scale, ln,
+                           stream);
 }

@@ -154,7 +154,8 @@ __device__ __forceinline__ void k_loop(const LoopCtx& c, unsigned char* lds, f32
 #undef WAIT
 }
 
-template <int EPI, typename OutT>
+// FOLD: LayerNorm folded into this GEMM (gemm_common.h): A is the raw bf16 residual row, the epilogue normalises.
+template <int EPI, typename OutT, bool FOLD = false>
 __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF_BYTES];
 
@@ -196,16 +197,20 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     issue_piece(PW0, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     issue_piece(PW1, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     issue_piece(PA1, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    float fa[FOLD ? 8 : 1], fb[FOLD ? 8 : 1];
+    if constexpr (FOLD) ln_row_coeffs<8>(p, m0 + wm * 128, lane, fa, fb);     // under the flight of the first K-tile
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     if (wm == 0) k_loop<true>(c, lds, acc); else k_loop<false>(c, lds, acc);
 
     // every fragment read finished before the last barrier: the whole LDS is free for the epilogue
+    if constexpr (FOLD) ln_apply<8>(p, acc, n0 + wn * 64, lane, fa, fb);
     const float4 no_pre[1] = {};
     unsigned char* eraw = lds + wave * EPI_WAVE_BYTES;
     if constexpr (EPI == EPI_STD && sizeof(OutT) == 4) {
-        if (p.residual) wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
+        if (p.residual && p.xb_out) wave_epilogue<EPI, OutT, 8, 1, true, 1, true>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
+        else if (p.residual) wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
         else wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
     } else {
         wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
@@ -224,7 +229,8 @@ int launch256(const GemmParams& p0, hipStream_t s) {
     p.chunk = g_chunk256;
     const int tiles = (p.M / BM) * (p.N / BN);
     PmTimer tm(FAM_GEMM, s);
-    hipLaunchKernelGGL((gemm256_kernel<EPI, OutT>), dim3(tiles), dim3(THREADS), 0, s, p);
+    if (p.ln_stats) hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, true>), dim3(tiles), dim3(THREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, false>), dim3(tiles), dim3(THREADS), 0, s, p);
     PM_HIP(hipGetLastError());
     return PMHIP_OK;
 }

@@ -24,6 +24,15 @@ struct GemmParams {
     float q_scale;
     int fast_math;                                 // SwiGLU: 1 = fast exp (bf16 mode)
     int chunk;                                     // n-tiles per L2 chunk of the tile walk (256x256 kernel)
+    // LayerNorm fold, producer side (EPI_STD, f32 out): also write the row as bf16 and, per 64-column chunk,
+    // (sum x, sum x^2) of the row -> stats_out[m][N/64][2]
+    bf16_t* xb_out; int ldxb;
+    float* stats_out;
+    // LayerNorm fold, consumer side (256x256 kernel): A is the RAW bf16 row, W carries gamma, and the epilogue applies
+    // out = rstd * acc - rstd * mean * c[n] + d[n] with (mean, rstd) from the producer's partial sums
+    const float* ln_stats; int ln_nc;              // [M][ln_nc][2], ln_nc = K / 64
+    const float* ln_c; const float* ln_d;          // [N]: c = sum_k bf16(gamma_k W_nk), d = sum_k beta_k W_nk
+    float ln_eps;
 };
 
 // XCD-aware, bijective block remap: consecutive virtual ids stay on one XCD's L2 (block b runs on XCD b % 8).
@@ -58,6 +67,52 @@ __device__ __forceinline__ float silu_mul(float x1, float x2, int fast) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm fold, consumer side.  ln_row_coeffs: (rstd, -rstd * mean) of the MI rows this lane owns in the
+// accumulator layout (row mwave + mi*16 + l15), from the producer's per-64-column partial sums.  Deterministic: the
+// partials are summed in chunk order.  ln_apply: acc = rstd * acc - rstd * mean * c[n] + d[n].
+// ------------------------------------------------------------------------------------------------
+template <int MI>
+__device__ __forceinline__ void ln_row_coeffs(const GemmParams& p, int mwave, int lane, float (&fa)[MI], float (&fb)[MI]) {
+    const int l15 = lane & 15;
+    const float invD = 1.0f / (float)(p.ln_nc * 64);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const float4* st = reinterpret_cast<const float4*>(p.ln_stats + (size_t)(mwave + mi * 16 + l15) * p.ln_nc * 2);
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = 0; c < p.ln_nc / 2; ++c) {                     // ln_nc is even (K is a multiple of 128)
+            const float4 t = st[c];
+            s1 += t.x; s2 += t.y; s1 += t.z; s2 += t.w;
+        }
+        const float mean = s1 * invD;
+        const float var = fmaxf(s2 * invD - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+        fa[mi] = rstd;
+        fb[mi] = -rstd * mean;
+    }
+}
+
+template <int MI>
+__device__ __forceinline__ void ln_apply(const GemmParams& p, f32x4_t (&acc)[MI][4], int nw, int lane, const float (&fa)[MI],
+                                         const float (&fb)[MI]) {
+    const int g = lane >> 4;
+    float4 cc[4], dd[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        cc[ni] = *reinterpret_cast<const float4*>(p.ln_c + nw + ni * 16 + g * 4);
+        dd[ni] = *reinterpret_cast<const float4*>(p.ln_d + nw + ni * 16 + g * 4);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            acc[mi][ni][0] = fa[mi] * acc[mi][ni][0] + (fb[mi] * cc[ni].x + dd[ni].x);
+            acc[mi][ni][1] = fa[mi] * acc[mi][ni][1] + (fb[mi] * cc[ni].y + dd[ni].y);
+            acc[mi][ni][2] = fa[mi] * acc[mi][ni][2] + (fb[mi] * cc[ni].z + dd[ni].z);
+            acc[mi][ni][3] = fa[mi] * acc[mi][ni][3] + (fb[mi] * cc[ni].w + dd[ni].w);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Wave-level epilogue for a (MI*16) x 64 accumulator tile held as acc[MI][4] (MFMA issued with W as the row
 // operand: a lane owns row l15 of a 16-row group and 4 consecutive columns per 16x16 tile).  The tile is
 // transposed 16 rows at a time through `eraw` (>= EPI_WAVE_BYTES of LDS nobody else touches) so that every
@@ -67,7 +122,7 @@ __device__ __forceinline__ float silu_mul(float x1, float x2, int fast) {
 // the store queue at every branch join).  RES: 1 / 0 = residual known present / absent at compile time (-1: runtime);
 // with FULL && RES == 1 the residual rows of slice mi+1 are requested before slice mi's stores are issued.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, typename OutT, int MI, int NPRE, bool FULL = false, int RES = -1>
+template <int EPI, typename OutT, int MI, int NPRE, bool FULL = false, int RES = -1, bool EMIT = false>
 __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][4], unsigned char* eraw, int mwave,
                                               int nw, int lane, const float4 (&rpre)[NPRE]) {
     constexpr int CPL = 16 / (int)sizeof(OutT);                    // columns per lane per store (16 B)
@@ -260,6 +315,18 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                         }
                     }
                     store_row(reinterpret_cast<OutT*>(p.out) + (size_t)mm * p.ldo + ncol, v);
+                    if constexpr (EMIT && sizeof(OutT) == 4) {
+                        // LayerNorm fold: the consumer GEMM reads this row as bf16; its statistics come from the f32 values
+                        store4(p.xb_out + (size_t)mm * p.ldxb + ncol, v[0], v[1], v[2], v[3]);
+                        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                        s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);            // the row's 64 columns sit in 16 adjacent lanes
+                        s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);
+                        s1 += dpp_mov<0x141>(s1); s2 += dpp_mov<0x141>(s2);
+                        s1 += dpp_mov<0x140>(s1); s2 += dpp_mov<0x140>(s2);
+                        if ((lane & 15) == 0)
+                            *reinterpret_cast<float2*>(p.stats_out + ((size_t)mm * (p.N >> 6) + (nw >> 6)) * 2) = make_float2(s1, s2);
+                    }
                 }
             }
         } else if constexpr (EPI == EPI_SWIGLU) {

@@ -106,6 +106,81 @@ def gemm_heads(a, w, heads, tokens, kinds, q_scale=1.0):
     return outs
 
 
+# ---- LayerNorm folded into the neighbouring GEMMs (include/pmhip.h, pmhip_lnfold) ---------------------------------
+def gemm_stats(a, w, bias=None, residual=None, res_rows=0):
+    """f32 GEMM that also emits the bf16 copy of its result and the per-64-column (sum x, sum x^2) partials."""
+    dev = _dev(a, w, bias, residual)
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, device=dev, dtype=torch.float32)
+    xb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    stats = torch.empty(M, N // 64, 2, device=dev, dtype=torch.float32)
+    ldr = residual.shape[-1] if residual is not None else 0
+    rr = res_rows or (residual.shape[0] if residual is not None else 0)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_gemm_stats(pm_dtype(a.dtype), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(residual), ldr, rr,
+                                   _p(out), N, _p(xb), N, _p(stats), M, N, K, stream_ptr(dev)), "pmhip_gemm_stats")
+    return out, xb, stats
+
+
+def _lnfold(stats, c, d, eps):
+    ln = _lib.LnFold()
+    ln.stats, ln.c, ln.d, ln.eps = C.c_void_p(stats.data_ptr()), C.c_void_p(c.data_ptr()), C.c_void_p(d.data_ptr()), float(eps)
+    return ln
+
+
+def lnfold_supported(kind, M, N, K):
+    return bool(_lib.load().pmhip_lnfold_supported(BF16, kind, M, N, K))
+
+
+def gemm_ln(xb, wg, stats, c, d, eps=1e-5, bias=None, out_dtype=None):
+    dev = _dev(xb, wg, stats, c, d)
+    lib = _lib.load()
+    M, K = xb.shape
+    N = wg.shape[0]
+    out_dtype = out_dtype or xb.dtype
+    out = torch.empty(M, N, device=dev, dtype=out_dtype)
+    ln = _lnfold(stats, c, d, eps)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_gemm_ln(pm_dtype(xb.dtype), _p(xb), xb.stride(0), _p(wg), wg.stride(0), _p(bias), _p(out), N,
+                                pm_dtype(out_dtype), M, N, K, C.byref(ln), stream_ptr(dev)), "pmhip_gemm_ln")
+    return out
+
+
+def gemm_swiglu_ln(xb, w12pg, b12p, stats, c, d, eps=1e-5):
+    dev = _dev(xb, w12pg, b12p)
+    lib = _lib.load()
+    M, K = xb.shape
+    Hp = w12pg.shape[0] // 2
+    out = torch.empty(M, Hp, device=dev, dtype=xb.dtype)
+    ln = _lnfold(stats, c, d, eps)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_gemm_swiglu_ln(pm_dtype(xb.dtype), _p(xb), xb.stride(0), _p(w12pg), _p(b12p), _p(out), Hp, M, Hp, K,
+                                       C.byref(ln), stream_ptr(dev)), "pmhip_gemm_swiglu_ln")
+    return out
+
+
+def gemm_heads_ln(xb, wg, heads, tokens, kinds, q_scale, stats, c, d, eps=1e-5):
+    dev = _dev(xb, wg)
+    lib = _lib.load()
+    M, K = xb.shape
+    B = M // tokens
+    tp = round_up(tokens, 64)
+    outs = []
+    for kind in kinds:
+        shape = (B, heads, tokens, 64) if kind == PART_Q else ((B, heads, tp, 64) if kind == PART_K else (B, heads, 64, tp))
+        outs.append(torch.zeros(shape, device=dev, dtype=xb.dtype))
+    kinds_c = (C.c_int * len(kinds))(*kinds)
+    outs_c = (C.c_void_p * len(kinds))(*[o.data_ptr() for o in outs])
+    ln = _lnfold(stats, c, d, eps)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_gemm_heads_ln(pm_dtype(xb.dtype), _p(xb), xb.stride(0), _p(wg), wg.stride(0), M, K, heads, tokens, tp,
+                                      len(kinds), kinds_c, outs_c, float(q_scale), C.byref(ln), stream_ptr(dev)),
+              "pmhip_gemm_heads_ln")
+    return outs
+
+
 def attention(q, k, vt, n_kv, use_exp2=False):
     """q [B,H,Nq,64], k [B,H,Nkp,64], vt [B,H,64,Nkp] -> [B*Nq, H*64]."""
     dev = _dev(q, k, vt)

@@ -57,6 +57,18 @@ def pack_w3(w3, hp, dtype):
     return pad_cols(w3.weight, hp, dtype)
 
 
+def ln_fold(w, gamma, beta, dtype=torch.bfloat16):
+    """LayerNorm folded into the Linear that consumes it (include/pmhip.h, pmhip_lnfold):
+    y . W^T = rstd * (x . Wg^T) - rstd * mean * c + d  with  Wg = gamma (.) W (rounded to `dtype`), c[n] = sum_k Wg[n,k]
+    (of the ROUNDED values, so the algebra matches what the matrix core multiplies), d[n] = sum_k beta[k] W[n,k].
+    w [N,K] in the packed row order the kernel consumes; returns (Wg [N,K] dtype, c [N] f32, d [N] f32)."""
+    w32 = w.detach().float()
+    wg = (w32 * gamma.detach().float()[None, :]).to(dtype).contiguous()
+    c = wg.float().sum(1).contiguous()
+    d = (w32 * beta.detach().float()[None, :]).sum(1).contiguous()
+    return wg, c, d
+
+
 def params_fingerprint(module):
     """Cheap identity+version stamp of every parameter: changes on load_state_dict / .to() / in-place edits."""
     return tuple((p.data_ptr(), p._version, p.dtype) for p in module.parameters())

@@ -97,6 +97,52 @@ def test_swiglu_and_heads_large_tile_kernel():
     assert rel_err(n(vt), full[:, :, 2].transpose(0, 2, 3, 1)) < 1e-2
 
 
+def test_layernorm_fold_producer_and_consumers():
+    """LayerNorm folded into its neighbour GEMMs (stage1/layers.py:54-58: every projection consumes LN(x)).
+    Producer: the residual GEMM also emits bf16(x) and the per-64-column (sum, sum of squares) partials -- the f32 result
+    must be bit-identical to the plain GEMM.  Consumers (plain / SwiGLU / head split): raw bf16 rows x gamma-scaled
+    weights + the epilogue formula against the float64 LayerNorm -> Linear, and against the unfused bf16 kernels."""
+    M, D, K0, heads = 4096, 512, 512, 8
+    bf = torch.bfloat16
+    a, w0, b0 = bf16_round(rnd(M, K0)), bf16_round(rnd(D, K0, scale=K0 ** -0.5)), rnd(D)
+    res = rnd(M, D) + 0.7                                   # non-zero row means
+    out, xb, stats = ops.gemm_stats(t(a, bf), t(w0, bf), bias=t(b0), residual=t(res))
+    plain = ops.gemm(t(a, bf), t(w0, bf), bias=t(b0), residual=t(res), out_dtype=torch.float32)
+    assert torch.equal(out, plain) and torch.equal(xb, out.to(bf))
+    x = n(out).astype(np.float64)
+    chunks = x.reshape(M, D // 64, 64)
+    assert rel_err(n(stats)[..., 0], chunks.sum(-1)) < 1e-5 and rel_err(n(stats)[..., 1], (chunks ** 2).sum(-1)) < 1e-5
+    gamma, beta = 1 + 0.3 * rnd(D), 0.2 * rnd(D)
+    y64 = (x - x.mean(1, keepdims=True)) / np.sqrt(x.var(1, keepdims=True) + 1e-5) * gamma + beta
+    y_dev = ops.layernorm(out, t(gamma), t(beta), out_dtype=bf)
+    # plain consumer (N = 1536 -> 96 tiles of 256x256), f32 result with bias
+    w1, b1 = bf16_round(rnd(1536, D, scale=D ** -0.5)), rnd(1536)
+    wg, c, d = packing.ln_fold(t(w1), t(gamma), t(beta))
+    got = n(ops.gemm_ln(xb, wg, stats, c, d, bias=t(b1), out_dtype=torch.float32))
+    want = y64 @ w1.astype(np.float64).T + b1
+    unfused = n(ops.gemm(y_dev, t(w1, bf), bias=t(b1), out_dtype=torch.float32))
+    assert rel_err(got, want) < 2e-2 and rel_err(unfused, want) < 2e-2, (rel_err(got, want), rel_err(unfused, want))
+    assert ops.lnfold_supported(0, M, 1536, D) and not ops.lnfold_supported(0, 256, 1536, D)
+    # head split (q | k | v)
+    wg, c, d = packing.ln_fold(t(w1), t(gamma), t(beta))
+    q, k, vt = ops.gemm_heads_ln(xb, wg, heads, 1024, [ops.PART_Q, ops.PART_K, ops.PART_V], 0.125, stats, c, d)
+    q2, k2, vt2 = ops.gemm_heads(y_dev, t(w1, bf), heads, 1024, [ops.PART_Q, ops.PART_K, ops.PART_V], 0.125)
+    proj = (y64 @ w1.astype(np.float64).T).reshape(4, 1024, 3, heads, 64)
+    assert rel_err(n(q), proj[:, :, 0].transpose(0, 2, 1, 3) * 0.125) < 2e-2
+    assert rel_err(n(k), proj[:, :, 1].transpose(0, 2, 1, 3)) < 2e-2 and rel_err(n(vt), proj[:, :, 2].transpose(0, 2, 3, 1)) < 2e-2
+    assert rel_err(n(q), n(q2)) < 2e-2 and rel_err(n(vt), n(vt2)) < 2e-2
+    # SwiGLU (hidden 1368 -> 1408 padded, packed rows)
+    lin = torch.nn.Linear(D, 2 * 1368)
+    w12p32, b12p, hp = packing.pack_w12(lin.to(dev()), torch.float32)
+    wg, c, d = packing.ln_fold(w12p32, t(gamma), t(beta))
+    hid = n(ops.gemm_swiglu_ln(xb, wg, b12p, stats, c, d))
+    hid2 = n(ops.gemm_swiglu(y_dev, w12p32.to(bf), b12p))
+    w12, b12 = n(lin.weight).astype(np.float64), n(lin.bias).astype(np.float64)
+    x12 = y64 @ w12.T + b12
+    ref = O.silu(x12[:, :1368].astype(np.float32)).astype(np.float64) * x12[:, 1368:]
+    assert rel_err(hid[:, :1368], ref) < 3e-2 and rel_err(hid2[:, :1368], ref) < 3e-2 and np.all(hid[:, 1368:] == 0)
+
+
 def test_gemm_is_transpose_correct_on_asymmetric_data():
     """A = identity-like selector, W asymmetric: catches a swapped (m,n) in the MFMA output mapping."""
     M = N = K = 128
