@@ -76,13 +76,13 @@ int pmhip_gemm_heads(int dtype, const void* A, int lda, const void* W, int ldw, 
  * the GEMM that CONSUMES LN(x) multiplies the raw bf16 x by the gamma-scaled weights and applies the formula in its
  * epilogue.  The separate LayerNorm pass (read 4 B + write 2 B per element) disappears.  Deterministic: no atomics. */
 typedef struct pmhip_lnfold {
-    const float* stats;   /* [M][K/64][2]: per row and 64-column chunk (sum x, sum x^2), written by pmhip_gemm_stats */
+    const float* stats;   /* [K/64][M][2] (chunk-major): per 64-column chunk and row (sum x, sum x^2), written by pmhip_gemm_stats */
     const float* c;       /* [N]: sum_k of the (rounded) gamma-scaled weight row */
     const float* d;       /* [N]: sum_k beta[k] * W[n,k] */
     float eps;            /* LayerNorm eps */
 } pmhip_lnfold;
 
-/* pmhip_gemm with an f32 result that ALSO emits xb_out[M,N] (bf16 copy, row stride ldxb) and stats_out[M][N/64][2].
+/* pmhip_gemm with an f32 result that ALSO emits xb_out[M,N] (bf16 copy, row stride ldxb) and stats_out[N/64][M][2].
  * N must be a multiple of 64. */
 int pmhip_gemm_stats(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
                      const float* residual, int ldr, int res_rows, float* out, int ldo, void* xb_out,
@@ -202,6 +202,10 @@ typedef struct pmhip_layer_weights {
     const float* ln2_g; const float* ln2_b;    /* the norm in front of the FFN                  */
     const void* w12p; const float* b12p;       /* packed SwiGLU w12, [2*hidden_pad, dim] T      */
     const void* w3p; const float* b3;          /* w3 zero-padded in K, [dim, hidden_pad] T      */
+    /* LayerNorm fold (bf16 mode; all NULL = not folded): gamma-scaled weights + the c / d vectors of pmhip_lnfold  */
+    const void* wqkv_f; const float* qkv_c; const float* qkv_d;        /* norm1 into attn1 q|k|v               */
+    const void* wqkv2_f; const float* qkv2_c; const float* qkv2_d;     /* stage 2: norm2 into attn2 q|k|v      */
+    const void* w12p_f; const float* w12_c; const float* w12_d;        /* the FFN norm into packed w12         */
 } pmhip_layer_weights;
 
 typedef struct pmhip_tower_cfg {
@@ -265,6 +269,7 @@ typedef struct pmhip_s2_weights {
     const pmhip_layer_weights* layers;         /* host array [depth]                            */
     const float* norm_g; const float* norm_b;
     const void* logits_w; const float* logits_b;     /* [n_embed, dim] T                       */
+    const void* logits_wf; const float* logits_c; const float* logits_d;   /* final norm folded into to_logits (or NULL) */
 } pmhip_s2_weights;
 
 typedef struct pmhip_s2 pmhip_s2;

@@ -26,7 +26,8 @@ class LayerWeights(C.Structure):
     """mirror of pmhip_layer_weights"""
     _fields_ = [(n, vp) for n in (
         "ln1_g", "ln1_b", "wqkv", "wo", "bo", "lnx_g", "lnx_b", "wqkv2", "wo2", "bo2",
-        "ln2_g", "ln2_b", "w12p", "b12p", "w3p", "b3")]
+        "ln2_g", "ln2_b", "w12p", "b12p", "w3p", "b3",
+        "wqkv_f", "qkv_c", "qkv_d", "wqkv2_f", "qkv2_c", "qkv2_d", "w12p_f", "w12_c", "w12_d")]
 
 
 class TowerCfg(C.Structure):
@@ -54,7 +55,7 @@ class S2Cfg(C.Structure):
 class S2Weights(C.Structure):
     _fields_ = [("tok_table", vp), ("tokproj_w", vp), ("tokproj_b", vp), ("pos", vp), ("ctxproj_w", vp),
                 ("layers", C.POINTER(LayerWeights)), ("norm_g", vp), ("norm_b", vp), ("logits_w", vp),
-                ("logits_b", vp)]
+                ("logits_b", vp), ("logits_wf", vp), ("logits_c", vp), ("logits_d", vp)]
 
 
 class LnFold(C.Structure):

@@ -145,7 +145,19 @@ struct TowerBufs {
     void* q = nullptr; void* k = nullptr; void* vt = nullptr;
     void* attn = nullptr;   // T [M, inner]
     void* hid = nullptr;    // T [M, hidden_pad]
+    float* stats = nullptr; // LayerNorm fold: per row and 64-column chunk (sum x, sum x^2) of the residual stream
+    // LayerNorm fold state of one forward pass.  fold: the handle is in bf16 mode and folding is enabled; stats_valid:
+    // `stats` and the bf16 copy of x (kept in `y`) describe the CURRENT x (its producer was a GEMM that emitted them)
+    bool fold = false, stats_valid = false;
 };
+
+// The LayerNorm fold is OPT-IN (PMHIP_LN_FOLD=1, read on every forward so that tests can switch it): it removes the
+// LayerNorm launches (432 -> 8 per bench step) but costs the consumer GEMMs ~1-2 us per tile, and with three concurrent
+// lanes the HBM-bound LayerNorm already hides under the other lanes' GEMMs: measured 401 vs 410 images/s.
+bool ln_fold_enabled() {
+    const char* e = getenv("PMHIP_LN_FOLD");
+    return e && atoi(e) != 0;
+}
 
 int alloc_tower(Workspace& ws, const char* tag, int dtype, const pmhip_tower_cfg& tc, int B, int tokens, TowerBufs& b,
                 hipStream_t s) {
@@ -160,7 +172,35 @@ int alloc_tower(Workspace& ws, const char* tag, int dtype, const pmhip_tower_cfg
     WS(ws, (t + ".vt").c_str(), (size_t)B * tc.heads * Np * 64 * es, b.vt);
     WS(ws, (t + ".attn").c_str(), M * inner * es, b.attn);
     WS(ws, (t + ".hid").c_str(), M * tc.hidden_pad * es, b.hid);
+    WS(ws, (t + ".stats").c_str(), M * (tc.dim / 64) * 2 * 4, b.stats);
+    b.fold = dtype == PMHIP_BF16 && ln_fold_enabled();
+    b.stats_valid = false;
     return PMHIP_OK;
+}
+
+// residual GEMM x = A . W^T + bias + residual (in place when residual == b.x).  With the fold on it also emits the bf16
+// copy of x into b.y and the row statistics, which lets the NEXT LayerNorm disappear into its consumer.
+int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual,
+                  int ldr, int res_rows, int M, int N, int K, hipStream_t s) {
+    if (b.fold && N % 64 == 0) {
+        PM_TRY(pmhip_gemm_stats(dtype, A, lda, W, ldw, bias, residual, ldr, res_rows, b.x, N, b.y, N, b.stats, M, N, K, s));
+        b.stats_valid = true;
+        return PMHIP_OK;
+    }
+    b.stats_valid = false;
+    return pmhip_gemm(dtype, A, lda, W, ldw, bias, residual, ldr, res_rows, b.x, N, PMHIP_F32, M, N, K, s);
+}
+
+// LN(x) -> head-split projection: folded when the statistics of x are at hand and the shape is served, else LayerNorm + GEMM
+int ln_heads(int dtype, TowerBufs& b, const float* g, const float* be, const void* W, const void* Wf, const float* fc, const float* fd,
+             int M, int dim, int heads, int tokens, int Np, int nparts, const int* kinds, void* const* outs, float q_scale, hipStream_t s) {
+    if (b.fold && b.stats_valid && Wf && pmhip_lnfold_supported(dtype, 2, M, nparts * heads * 64, dim)) {
+        const pmhip_lnfold ln{b.stats, fc, fd, 1e-5f};
+        return pmhip_gemm_heads_ln(dtype, b.y, dim, Wf, dim, M, dim, heads, tokens, Np, nparts, kinds, outs, q_scale, &ln, s);
+    }
+    PM_TRY(pmhip_layernorm(b.x, g, be, 1e-5f, b.y, dtype, M, dim, s));
+    b.stats_valid = false;                                     // b.y now holds LN(x), not bf16(x)
+    return pmhip_gemm_heads(dtype, b.y, dim, W, dim, M, dim, heads, tokens, Np, nparts, kinds, outs, q_scale, s);
 }
 
 // one pre-LN transformer block (stage1/layers.py:54-58; stage2/transformer.py:44-49)
@@ -173,36 +213,41 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
     const float eps = 1e-5f;
 
     // x = attn1(norm1(x)) + x
-    PM_TRY(pmhip_layernorm(b.x, L.ln1_g, L.ln1_b, eps, b.y, dtype, M, dim, s));
     {
         void* outs[3] = {b.q, b.k, b.vt};
-        PM_TRY(pmhip_gemm_heads(dtype, b.y, dim, L.wqkv, dim, M, dim, tc.heads, tokens, Np, 3, kinds_qkv, outs, q_scale, s));
+        PM_TRY(ln_heads(dtype, b, L.ln1_g, L.ln1_b, L.wqkv, L.wqkv_f, L.qkv_c, L.qkv_d, M, dim, tc.heads, tokens, Np, 3, kinds_qkv, outs,
+                        q_scale, s));
     }
     PM_TRY(pmhip_attention(dtype, b.q, b.k, b.vt, b.attn, inner, B, tc.heads, tokens, tokens, Np, fast, s));
-    PM_TRY(pmhip_gemm(dtype, b.attn, inner, L.wo, inner, L.bo, b.x, dim, M, b.x, dim, PMHIP_F32, M, dim, inner, s));
+    PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo, inner, L.bo, b.x, dim, M, M, dim, inner, s));
 
     if (stage2) {
         // x = attn2(norm2(x), context) + x ; context None -> a second self-attention (attention.py:47)
-        PM_TRY(pmhip_layernorm(b.x, L.lnx_g, L.lnx_b, eps, b.y, dtype, M, dim, s));
         if (cross && cross->k) {
             const int kind_q[1] = {PMHIP_PART_Q};
             void* outs[1] = {b.q};
-            PM_TRY(pmhip_gemm_heads(dtype, b.y, dim, L.wqkv2, dim, M, dim, tc.heads, tokens, Np, 1, kind_q, outs, q_scale, s));
+            PM_TRY(ln_heads(dtype, b, L.lnx_g, L.lnx_b, L.wqkv2, L.wqkv2_f, L.qkv2_c, L.qkv2_d, M, dim, tc.heads, tokens, Np, 1, kind_q,
+                            outs, q_scale, s));
             PM_TRY(pmhip_attention(dtype, b.q, cross->k, cross->vt, b.attn, inner, B, tc.heads, tokens, cross->L, cross->Lp, fast, s));
         } else {
             void* outs[3] = {b.q, b.k, b.vt};
-            PM_TRY(pmhip_gemm_heads(dtype, b.y, dim, L.wqkv2, dim, M, dim, tc.heads, tokens, Np, 3, kinds_qkv, outs, q_scale, s));
+            PM_TRY(ln_heads(dtype, b, L.lnx_g, L.lnx_b, L.wqkv2, L.wqkv2_f, L.qkv2_c, L.qkv2_d, M, dim, tc.heads, tokens, Np, 3, kinds_qkv,
+                            outs, q_scale, s));
             PM_TRY(pmhip_attention(dtype, b.q, b.k, b.vt, b.attn, inner, B, tc.heads, tokens, tokens, Np, fast, s));
         }
-        PM_TRY(pmhip_gemm(dtype, b.attn, inner, L.wo2, inner, L.bo2, b.x, dim, M, b.x, dim, PMHIP_F32, M, dim, inner, s));
+        PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo2, inner, L.bo2, b.x, dim, M, M, dim, inner, s));
     }
 
     // x = ffnet(norm(x)) + x
-    PM_TRY(pmhip_layernorm(b.x, L.ln2_g, L.ln2_b, eps, b.y, dtype, M, dim, s));
-    PM_TRY(pmhip_gemm_swiglu(dtype, b.y, dim, L.w12p, L.b12p, b.hid, tc.hidden_pad, M, tc.hidden_pad, dim, s));
-    PM_TRY(pmhip_gemm(dtype, b.hid, tc.hidden_pad, L.w3p, tc.hidden_pad, L.b3, b.x, dim, M, b.x, dim, PMHIP_F32, M, dim,
-                      tc.hidden_pad, s));
-    return PMHIP_OK;
+    if (b.fold && b.stats_valid && L.w12p_f && pmhip_lnfold_supported(dtype, 1, M, 2 * tc.hidden_pad, dim)) {
+        const pmhip_lnfold ln{b.stats, L.w12_c, L.w12_d, eps};
+        PM_TRY(pmhip_gemm_swiglu_ln(dtype, b.y, dim, L.w12p_f, L.b12p, b.hid, tc.hidden_pad, M, tc.hidden_pad, dim, &ln, s));
+    } else {
+        PM_TRY(pmhip_layernorm(b.x, L.ln2_g, L.ln2_b, eps, b.y, dtype, M, dim, s));
+        b.stats_valid = false;
+        PM_TRY(pmhip_gemm_swiglu(dtype, b.y, dim, L.w12p, L.b12p, b.hid, tc.hidden_pad, M, tc.hidden_pad, dim, s));
+    }
+    return residual_gemm(dtype, b, b.hid, tc.hidden_pad, L.w3p, tc.hidden_pad, L.b3, b.x, dim, M, M, dim, tc.hidden_pad, s);
 }
 
 }  // namespace
@@ -293,8 +338,7 @@ int vq_decode_latent(pmhip_vqgan* h, const void* zp, int B, float* img_out, hipS
     TowerBufs tb;
     PM_TRY(alloc_tower(h->ws, "dec", h->dtype, c.dec, B, h->tokens, tb, s));
     // post_quant + position embedding fused (vqmodel.py:28, layers.py:146)
-    PM_TRY(pmhip_gemm(h->dtype, zp, 64, h->w.postq_w, 64, h->w.postq_b, h->w.dec_pos, dim, h->tokens, tb.x, dim, PMHIP_F32,
-                      M, dim, 64, s));
+    PM_TRY(residual_gemm(h->dtype, tb, zp, 64, h->w.postq_w, 64, h->w.postq_b, h->w.dec_pos, dim, h->tokens, M, dim, 64, s));
     return vq_decoder_tower(h, tb, B, img_out, true, s);
 }
 
@@ -457,10 +501,14 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s) {
     const int M = B * c.tokens, dim = c.tower.dim;
     TowerBufs tb;
     PM_TRY(alloc_tower(h->ws, "s2", h->dtype, c.tower, B, c.tokens, tb, s));
-    PM_TRY(pmhip_gemm(h->dtype, tp, 64, h->w.tokproj_w, 64, h->w.tokproj_b, h->w.pos, dim, c.tokens, tb.x, dim, PMHIP_F32, M,
-                      dim, 64, s));
+    PM_TRY(residual_gemm(h->dtype, tb, tp, 64, h->w.tokproj_w, 64, h->w.tokproj_b, h->w.pos, dim, c.tokens, M, dim, 64, s));
     for (int l = 0; l < c.tower.depth; ++l)
         PM_TRY(layer_forward(h->dtype, h->layers[l], c.tower, tb, B, c.tokens, true, &h->cross[l], s));
+    if (tb.fold && tb.stats_valid && h->w.logits_wf && pmhip_lnfold_supported(h->dtype, 0, M, c.n_embed, dim)) {
+        const pmhip_lnfold ln{tb.stats, h->w.logits_c, h->w.logits_d, 1e-5f};      // the final norm folded into to_logits
+        return pmhip_gemm_ln(h->dtype, tb.y, dim, h->w.logits_wf, dim, h->w.logits_b, logits, c.n_embed, PMHIP_F32, M, c.n_embed, dim,
+                             &ln, s);
+    }
     PM_TRY(pmhip_layernorm(tb.x, h->w.norm_g, h->w.norm_b, 1e-5f, tb.y, h->dtype, M, dim, s));
     return pmhip_gemm(h->dtype, tb.y, dim, h->w.logits_w, dim, h->w.logits_b, nullptr, 0, 0, logits, c.n_embed, PMHIP_F32, M,
                       c.n_embed, dim, s);

@@ -157,7 +157,7 @@ __device__ __forceinline__ void k_loop(const LoopCtx& c, unsigned char* lds, f32
 // FOLD: LayerNorm folded into this GEMM (gemm_common.h): A is the raw bf16 residual row, the epilogue normalises.
 template <int EPI, typename OutT, bool FOLD = false>
 __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF_BYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF_BYTES + (FOLD ? 8 * 2048 : 0)];   // + 2 KiB per wave for the fold
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -193,19 +193,22 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // prologue: the whole first K-tile, in need-order; PA0 + PW0 must have landed before phase 1
+    LnLoads lnl;
+    if constexpr (FOLD) ln_stats_issue(p, m0 + wm * 128, n0 + wn * 64, lane, lnl);      // before the DMA: these return first
     issue_piece(PA0, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     issue_piece(PW0, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     issue_piece(PW1, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     issue_piece(PA1, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     float fa[FOLD ? 8 : 1], fb[FOLD ? 8 : 1];
-    if constexpr (FOLD) ln_row_coeffs<8>(p, m0 + wm * 128, lane, fa, fb);     // under the flight of the first K-tile
+    float* fscr = reinterpret_cast<float*>(lds + 2 * BUF_BYTES + (FOLD ? wave * 2048 : 0));
+    if constexpr (FOLD) ln_row_coeffs<8>(p, lane, fscr, lnl, fa, fb);        // 4 pieces x 2 DMA instructions stay in flight
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     if (wm == 0) k_loop<true>(c, lds, acc); else k_loop<false>(c, lds, acc);
 
     // every fragment read finished before the last barrier: the whole LDS is free for the epilogue
-    if constexpr (FOLD) ln_apply<8>(p, acc, n0 + wn * 64, lane, fa, fb);
+    if constexpr (FOLD) ln_apply<8>(fscr, acc, lane, fa, fb);
     const float4 no_pre[1] = {};
     unsigned char* eraw = lds + wave * EPI_WAVE_BYTES;
     if constexpr (EPI == EPI_STD && sizeof(OutT) == 4) {

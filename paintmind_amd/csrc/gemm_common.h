@@ -25,12 +25,12 @@ struct GemmParams {
     int fast_math;                                 // SwiGLU: 1 = fast exp (bf16 mode)
     int chunk;                                     // n-tiles per L2 chunk of the tile walk (256x256 kernel)
     // LayerNorm fold, producer side (EPI_STD, f32 out): also write the row as bf16 and, per 64-column chunk,
-    // (sum x, sum x^2) of the row -> stats_out[m][N/64][2]
+    // (sum x, sum x^2) of the row -> stats_out[N/64][m][2] (chunk-major)
     bf16_t* xb_out; int ldxb;
     float* stats_out;
     // LayerNorm fold, consumer side (256x256 kernel): A is the RAW bf16 row, W carries gamma, and the epilogue applies
     // out = rstd * acc - rstd * mean * c[n] + d[n] with (mean, rstd) from the producer's partial sums
-    const float* ln_stats; int ln_nc;              // [M][ln_nc][2], ln_nc = K / 64
+    const float* ln_stats; int ln_nc;              // [ln_nc][M][2], ln_nc = K / 64
     const float* ln_c; const float* ln_d;          // [N]: c = sum_k bf16(gamma_k W_nk), d = sum_k beta_k W_nk
     float ln_eps;
 };
@@ -71,35 +71,72 @@ __device__ __forceinline__ float silu_mul(float x1, float x2, int fast) {
 // accumulator layout (row mwave + mi*16 + l15), from the producer's per-64-column partial sums.  Deterministic: the
 // partials are summed in chunk order.  ln_apply: acc = rstd * acc - rstd * mean * c[n] + d[n].
 // ------------------------------------------------------------------------------------------------
-template <int MI>
-__device__ __forceinline__ void ln_row_coeffs(const GemmParams& p, int mwave, int lane, float (&fa)[MI], float (&fb)[MI]) {
+// Statistics layout: stats[chunk][row][2] (chunk-major), so that for one chunk the 128 rows of a wave are 1 KiB of
+// contiguous memory: lane j fetches rows 2j and 2j+1 of every chunk with ONE coalesced 16-byte load per chunk, all
+// issued before the first is consumed (one memory round trip).  The (rstd, -rstd*mean) pairs then go through `scratch`
+// (LDS private to the wave) so that each lane picks up the 8 rows it owns in the accumulator layout; the wave's 64
+// entries of c and d ride along into scratch[256 .. 383] so the epilogue reads them from LDS.
+// The loads are inline asm: hipcc would otherwise wait vmcnt(0) -- draining the LDS-DMA of the first K-tile that is in
+// flight at the same time -- before their first use.  ln_stats_issue goes BEFORE the DMA pieces are issued,
+// ln_row_coeffs after them with `dma_in_flight` = the number of DMA instructions issued in between (counted wait).
+constexpr int LN_MAXC = 16;
+struct LnLoads { f32x4_t t[LN_MAXC]; f32x4_t cd; };
+
+__device__ __forceinline__ void ln_stats_issue(const GemmParams& p, int mwave, int nw, int lane, LnLoads& L) {
+    const float* st = p.ln_stats + ((size_t)mwave + 2 * lane) * 2;
+    const size_t cstride = (size_t)p.M * 2;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        if (c < p.ln_nc) {                                          // wave-uniform (scalar branch): no per-lane predication
+            const float* a = st + c * cstride;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(L.t[c]) : "v"(a) : "memory");
+        }
+    }
+    const float* cda = (lane < 16 ? p.ln_c : p.ln_d) + nw + (lane & 15) * 4;      // lanes >= 32 re-read lanes 0-31's addresses
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(L.cd) : "v"(cda) : "memory");
+}
+
+template <int DMA_IN_FLIGHT>
+__device__ __forceinline__ void ln_row_coeffs(const GemmParams& p, int lane, float* scratch, LnLoads& L, float (&fa)[8], float (&fb)[8]) {
     const int l15 = lane & 15;
+    // every statistics load is older than the DMA instructions: leave exactly those in flight
+    asm volatile("s_waitcnt vmcnt(%17)"
+                 : "+v"(L.t[0]), "+v"(L.t[1]), "+v"(L.t[2]), "+v"(L.t[3]), "+v"(L.t[4]), "+v"(L.t[5]), "+v"(L.t[6]), "+v"(L.t[7]),
+                   "+v"(L.t[8]), "+v"(L.t[9]), "+v"(L.t[10]), "+v"(L.t[11]), "+v"(L.t[12]), "+v"(L.t[13]), "+v"(L.t[14]), "+v"(L.t[15]),
+                   "+v"(L.cd)
+                 : "n"(DMA_IN_FLIGHT) : "memory");
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c)
+        if (c < p.ln_nc) { s[0] += L.t[c][0]; s[1] += L.t[c][1]; s[2] += L.t[c][2]; s[3] += L.t[c][3]; }      // chunk order: deterministic
     const float invD = 1.0f / (float)(p.ln_nc * 64);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const float4* st = reinterpret_cast<const float4*>(p.ln_stats + (size_t)(mwave + mi * 16 + l15) * p.ln_nc * 2);
-        float s1 = 0.f, s2 = 0.f;
-        for (int c = 0; c < p.ln_nc / 2; ++c) {                     // ln_nc is even (K is a multiple of 128)
-            const float4 t = st[c];
-            s1 += t.x; s2 += t.y; s1 += t.z; s2 += t.w;
-        }
-        const float mean = s1 * invD;
-        const float var = fmaxf(s2 * invD - mean * mean, 0.f);
+    for (int r = 0; r < 2; ++r) {
+        const float mean = s[2 * r] * invD;
+        const float var = fmaxf(s[2 * r + 1] * invD - mean * mean, 0.f);
         const float rstd = 1.0f / sqrtf(var + p.ln_eps);
-        fa[mi] = rstd;
-        fb[mi] = -rstd * mean;
+        *reinterpret_cast<float2*>(scratch + (2 * lane + r) * 2) = make_float2(rstd, -rstd * mean);
+    }
+    if (lane < 32) *reinterpret_cast<f32x4_t*>(scratch + 256 + lane * 4) = L.cd;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const float2 ab = *reinterpret_cast<const float2*>(scratch + (mi * 16 + l15) * 2);
+        fa[mi] = ab.x;
+        fb[mi] = ab.y;
     }
 }
 
 template <int MI>
-__device__ __forceinline__ void ln_apply(const GemmParams& p, f32x4_t (&acc)[MI][4], int nw, int lane, const float (&fa)[MI],
+__device__ __forceinline__ void ln_apply(const float* scratch, f32x4_t (&acc)[MI][4], int lane, const float (&fa)[MI],
                                          const float (&fb)[MI]) {
     const int g = lane >> 4;
     float4 cc[4], dd[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-        cc[ni] = *reinterpret_cast<const float4*>(p.ln_c + nw + ni * 16 + g * 4);
-        dd[ni] = *reinterpret_cast<const float4*>(p.ln_d + nw + ni * 16 + g * 4);
+        cc[ni] = *reinterpret_cast<const float4*>(scratch + 256 + ni * 16 + g * 4);
+        dd[ni] = *reinterpret_cast<const float4*>(scratch + 256 + 64 + ni * 16 + g * 4);
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -325,7 +362,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                         s1 += dpp_mov<0x141>(s1); s2 += dpp_mov<0x141>(s2);
                         s1 += dpp_mov<0x140>(s1); s2 += dpp_mov<0x140>(s2);
                         if ((lane & 15) == 0)
-                            *reinterpret_cast<float2*>(p.stats_out + ((size_t)mm * (p.N >> 6) + (nw >> 6)) * 2) = make_float2(s1, s2);
+                            *reinterpret_cast<float2*>(p.stats_out + ((size_t)(nw >> 6) * p.M + mm) * 2) = make_float2(s1, s2);     // [chunk][row][2]
                     }
                 }
             }

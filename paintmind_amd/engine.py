@@ -47,6 +47,17 @@ def _pack_layer(layer, dtype, keep, stage2):
     w12p, b12p, hp = packing.pack_w12(layer.ffnet.w12, dtype)
     lw.w12p, lw.b12p = keep(w12p), keep(b12p)
     lw.w3p, lw.b3 = keep(packing.pack_w3(layer.ffnet.w3, hp, dtype)), keep(_f32(layer.ffnet.w3.bias))
+    if dtype == torch.bfloat16:
+        # LayerNorm fold (include/pmhip.h, pmhip_lnfold): gamma-scaled copies of the weights that consume a LayerNorm
+        def fold(w32, norm):
+            wg, c, d = packing.ln_fold(w32, norm.weight, norm.bias, dtype)
+            return keep(wg), keep(c), keep(d)
+        lw.wqkv_f, lw.qkv_c, lw.qkv_d = fold(packing.pack_qkv(a1.to_q, a1.to_k, a1.to_v, torch.float32), layer.norm1)
+        if stage2:
+            a2 = layer.attn2
+            if a2.to_k.in_features == a2.to_q.in_features:      # always true in the reference (context is pre-projected)
+                lw.wqkv2_f, lw.qkv2_c, lw.qkv2_d = fold(packing.pack_qkv(a2.to_q, a2.to_k, a2.to_v, torch.float32), layer.norm2)
+        lw.w12p_f, lw.w12_c, lw.w12_d = fold(packing.pack_w12(layer.ffnet.w12, torch.float32)[0], ffn_norm)
     return lw, hp
 
 
@@ -209,6 +220,9 @@ class S2Engine:
             w.layers = arr
             w.norm_g, w.norm_b = keep(_f32(tr.norm.weight)), keep(_f32(tr.norm.bias))
             w.logits_w, w.logits_b = keep(packing.cast(tr.to_logits.weight, dtype)), keep(_f32(tr.to_logits.bias))
+            if dtype == torch.bfloat16:
+                wg, c, d = packing.ln_fold(tr.to_logits.weight, tr.norm.weight, tr.norm.bias, dtype)
+                w.logits_wf, w.logits_c, w.logits_d = keep(wg), keep(c), keep(d)
             torch.cuda.synchronize(dev)
         cfg = S2Cfg()
         cfg.tokens = tr.position_embedding.shape[1]

@@ -115,7 +115,7 @@ def gemm_stats(a, w, bias=None, residual=None, res_rows=0):
     N = w.shape[0]
     out = torch.empty(M, N, device=dev, dtype=torch.float32)
     xb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    stats = torch.empty(M, N // 64, 2, device=dev, dtype=torch.float32)
+    stats = torch.empty(N // 64, M, 2, device=dev, dtype=torch.float32)      # chunk-major
     ldr = residual.shape[-1] if residual is not None else 0
     rr = res_rows or (residual.shape[0] if residual is not None else 0)
     with torch.cuda.device(dev):

@@ -117,3 +117,42 @@ def test_concurrent_lanes_are_deterministic_at_dim_1024():
         torch.cuda.synchronize()
         bad += sum(int(not torch.equal(a, b)) for a, b in zip(res, ref))
     assert bad == 0, f"{bad} / 600 concurrent forwards differ from the sequential result"
+
+
+def test_layernorm_fold_option_full_size(pipe512, monkeypatch):
+    """PMHIP_LN_FOLD=1 (opt-in): the LayerNorm passes disappear into the GEMMs either side (432 -> 8 launches per bench
+    step).  Same maths up to bf16 rounding of the raw residual row instead of the normalised row: the folded bf16
+    forward must sit as close to the fp32-verify logits as the unfolded one, and the folded decode loop must be
+    deterministic and bit-identical between the graph / lanes path and the eager single stream."""
+    from paintmind_amd import ops
+    pipe = pipe512
+    _, d = load_golden("full_stage2.npz")
+    ids0 = t(np.repeat(d["ids0"].astype(np.int64), 16, axis=0))            # 16 images: every consumer GEMM is fold-eligible
+    tok = pipe.ids2tokens(ids0)
+    l32 = pipe.tokens2logits(tok[:1], None)
+    pipe.set_compute_dtype(torch.bfloat16)
+    try:
+        monkeypatch.setenv("PMHIP_LN_FOLD", "0")
+        plain = pipe.tokens2logits(tok, None)
+        ops.timing_reset(); ops.timing_enable(True)
+        pipe.tokens2logits(tok, None)
+        torch.cuda.synchronize(); ops.timing_enable(False)
+        ln_plain = ops.timing_get("layernorm")[0]
+        monkeypatch.setenv("PMHIP_LN_FOLD", "1")
+        fold = pipe.tokens2logits(tok, None)
+        ops.timing_reset(); ops.timing_enable(True)
+        pipe.tokens2logits(tok, None)
+        torch.cuda.synchronize(); ops.timing_enable(False)
+        ln_fold = ops.timing_get("layernorm")[0]
+        assert ln_plain == 37 and ln_fold == 0, (ln_plain, ln_fold)       # 12 layers x 3 + the final norm
+        assert torch.equal(fold[:1], fold[7:8])                            # batch-invariant
+        e_plain, e_fold = float((plain[:1] - l32).abs().max()), float((fold[:1] - l32).abs().max())
+        print(f"logits max err vs fp32: unfolded {e_plain:.5f} folded {e_fold:.5f}")
+        assert e_fold < BF16_LOGIT_MAXERR and e_fold < 2.0 * e_plain + 1e-3
+        flags = [True] * 4
+        a = pipe.generate_ids(None, 16, 4, 1.0, 5, flags, seed=3, use_graph=False, streams=1)
+        for _ in range(3):
+            b = pipe.generate_ids(None, 16, 4, 1.0, 5, flags, seed=3, use_graph=True, streams=2)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    finally:
+        pipe.set_compute_dtype(torch.float32)
