@@ -75,7 +75,7 @@ struct LoopCtx {
 // slot behind ({MFMAs of the previous phase | reads}).  Both versions execute the SAME sequence of barriers, DMA
 // issues and vmcnt waits; they are separate straight-line loops so that no register is merged across roles.
 template <bool LEAD>
-__device__ __forceinline__ void k_loop(const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4]) {
+__device__ __forceinline__ void k_loop(const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], int pb) {
     uint4 a[4][2], w[2][2];                        // [fragment][kk]
     // Fragment reads are inline-asm ds_read_b128: hipcc would otherwise put `s_waitcnt vmcnt(0)` in front of every
     // LDS read while a DMA (an LDS write on the VM counter) is in flight and drain the pipeline each phase.  The
@@ -110,10 +110,10 @@ __device__ __forceinline__ void k_loop(const LoopCtx& c, unsigned char* lds, f32
 
     for (int kt = 0; kt < c.nk; ++kt) {
         const bool has_next = kt + 1 < c.nk;
-        const unsigned boff = (unsigned)(kt & 1) * BUF_BYTES;       // LDS byte addresses of this K-tile's fragments
+        const unsigned boff = (unsigned)((kt + pb) & 1) * BUF_BYTES;   // LDS byte addresses of this K-tile's fragments (pb: buffer of K-tile 0)
         const unsigned ba0 = c.lds_base + boff + c.fa0, ba1 = c.lds_base + boff + c.fa1;
         const unsigned bw0 = c.lds_base + boff + c.fw0, bw1 = c.lds_base + boff + c.fw1;
-        unsigned char* nxt = lds + ((kt + 1) & 1) * BUF_BYTES;
+        unsigned char* nxt = lds + ((kt + 1 + pb) & 1) * BUF_BYTES;
         // Every wave issues its DMA piece in ITS fragment-read slot (lead: first slot, lag: second slot), i.e. while the
         // other wave of the SIMD runs MFMAs: a DMA instruction holds the issuing wave for ~60 cycles, which in front of
         // the lag wave's MFMAs (with the lead wave busy reading) would idle the matrix pipe.  The piece still precedes
@@ -165,14 +165,14 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
 
-    int tm, tn;
-    tile_of_block(xcd_remap(blockIdx.x, gridDim.x), p.M / BM, p.N / BN, p.chunk, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-
+    // PERSISTENT: the grid holds at most one workgroup per CU; workgroup w walks tiles w, w + grid, ... of the same XCD /
+    // L2-aware order.  While a tile's epilogue runs, the first K-tile of the NEXT tile is already in flight (issued from
+    // the epilogue's hook into the LDS buffer the epilogue does not stage through), so only the first tile of a
+    // workgroup pays the DMA latency of its prologue, and a tile's stores drain under the next tile's K loop.
+    const int ntiles = (p.M / BM) * (p.N / BN);
+    const int tiles_m = p.M / BM, tiles_n = p.N / BN;
     LoopCtx c;
     c.lda_b = (size_t)p.lda * 2; c.ldw_b = (size_t)p.ldw * 2;
-    c.Ab = reinterpret_cast<const unsigned char*>(p.A) + (size_t)m0 * c.lda_b;
-    c.Wb = reinterpret_cast<const unsigned char*>(p.W) + (size_t)n0 * c.ldw_b;
     const unsigned lswz = (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);       // chunk rows start at multiples of 8
     c.laneoffA = (unsigned)(lane >> 3) * (unsigned)c.lda_b + lswz;
     c.laneoffW = (unsigned)(lane >> 3) * (unsigned)c.ldw_b + lswz;
@@ -186,13 +186,17 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     c.wave = wave;
     c.lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto origin = [&](int tile, int& m0, int& n0) {
+        int tm, tn;
+        tile_of_block(xcd_remap(tile, ntiles), tiles_m, tiles_n, p.chunk, tm, tn);
+        m0 = tm * BM; n0 = tn * BN;
+    };
+    int tile = blockIdx.x, m0, n0;
+    origin(tile, m0, n0);
+    c.Ab = reinterpret_cast<const unsigned char*>(p.A) + (size_t)m0 * c.lda_b;
+    c.Wb = reinterpret_cast<const unsigned char*>(p.W) + (size_t)n0 * c.ldw_b;
 
-    // prologue: the whole first K-tile, in need-order; PA0 + PW0 must have landed before phase 1
+    // prologue of the FIRST tile: its whole first K-tile, in need-order; PA0 + PW0 must have landed before phase 1
     LnLoads lnl;
     if constexpr (FOLD) ln_stats_issue(p, m0 + wm * 128, n0 + wn * 64, lane, lnl);      // before the DMA: these return first
     issue_piece(PA0, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
@@ -205,18 +209,54 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    if (wm == 0) k_loop<true>(c, lds, acc); else k_loop<false>(c, lds, acc);
+    int pb = 0;                                    // LDS buffer that holds K-tile 0 of the current tile
+    for (;;) {
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // every fragment read finished before the last barrier: the whole LDS is free for the epilogue
-    if constexpr (FOLD) ln_apply<8>(fscr, acc, lane, fa, fb);
-    const float4 no_pre[1] = {};
-    unsigned char* eraw = lds + wave * EPI_WAVE_BYTES;
-    if constexpr (EPI == EPI_STD && sizeof(OutT) == 4) {
-        if (p.residual && p.xb_out) wave_epilogue<EPI, OutT, 8, 1, true, 1, true>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
-        else if (p.residual) wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
-        else wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
-    } else {
-        wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
+        if (wm == 0) k_loop<true>(c, lds, acc, pb); else k_loop<false>(c, lds, acc, pb);
+
+        // every fragment read finished before the last barrier: both LDS buffers are free.  The epilogue stages through
+        // buffer 0 (8 KiB per wave); the next tile's first K-tile goes to buffer 1.
+        const int next = FOLD ? ntiles : tile + (int)gridDim.x;       // the fold variant is launched one tile per workgroup
+        const bool has_next = next < ntiles;
+        int m1 = 0, n1 = 0;
+        if (has_next) origin(next, m1, n1);
+        const unsigned char* Ab1 = reinterpret_cast<const unsigned char*>(p.A) + (size_t)m1 * c.lda_b;
+        const unsigned char* Wb1 = reinterpret_cast<const unsigned char*>(p.W) + (size_t)n1 * c.ldw_b;
+        auto prefetch = [&]() {
+            if (has_next) {
+                unsigned char* b1 = lds + BUF_BYTES;
+                issue_piece(PA0, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+                issue_piece(PW0, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+                issue_piece(PW1, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+                issue_piece(PA1, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+            }
+        };
+        if constexpr (FOLD) ln_apply<8>(fscr, acc, lane, fa, fb);
+        const float4 no_pre[1] = {};
+        unsigned char* eraw = lds + wave * EPI_WAVE_BYTES;
+        const int mw = m0 + wm * 128, nw = n0 + wn * 64;
+        if constexpr (EPI == EPI_STD && sizeof(OutT) == 4) {
+            // residual variants load through the whole epilogue (pipelined residual rows): no early prefetch there
+            if (p.residual && p.xb_out) { wave_epilogue<EPI, OutT, 8, 1, true, 1, true>(p, acc, eraw, mw, nw, lane, no_pre); prefetch(); }
+            else if (p.residual) { wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, mw, nw, lane, no_pre); prefetch(); }
+            else wave_epilogue<EPI, OutT, 8, 1, true, 0, false>(p, acc, eraw, mw, nw, lane, no_pre, prefetch);
+        } else {
+            wave_epilogue<EPI, OutT, 8, 1, true, 0, false>(p, acc, eraw, mw, nw, lane, no_pre, prefetch);
+        }
+        if (!has_next) break;
+        // the 8 DMA instructions of the prefetch are older than every store issued after the hook (>= 8 per wave in every
+        // epilogue), and vmcnt retires in issue order: with at most 4 operations left in flight those are stores, i.e. the
+        // whole K-tile has landed, while the youngest stores keep draining under the next K loop
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave is done staging through buffer 0; the K-tile is visible
+        tile = next; m0 = m1; n0 = n1;
+        c.Ab = Ab1; c.Wb = Wb1;
+        pb = 1;
     }
 }
 
@@ -231,9 +271,12 @@ int launch256(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.chunk = g_chunk256;
     const int tiles = (p.M / BM) * (p.N / BN);
+    static int persist = -1;                     // PMHIP_PERSIST256: workgroups of the persistent grid (0 = one per tile)
+    if (persist < 0) { const char* e = getenv("PMHIP_PERSIST256"); persist = e ? atoi(e) : 256; }
+    const int grid = (persist > 0 && tiles > persist) ? persist : tiles;
     PmTimer tm(FAM_GEMM, s);
     if (p.ln_stats) hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, true>), dim3(tiles), dim3(THREADS), 0, s, p);
-    else hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, false>), dim3(tiles), dim3(THREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, false>), dim3(grid), dim3(THREADS), 0, s, p);
     PM_HIP(hipGetLastError());
     return PMHIP_OK;
 }

@@ -159,9 +159,14 @@ __device__ __forceinline__ void ln_apply(const float* scratch, f32x4_t (&acc)[MI
 // the store queue at every branch join).  RES: 1 / 0 = residual known present / absent at compile time (-1: runtime);
 // with FULL && RES == 1 the residual rows of slice mi+1 are requested before slice mi's stores are issued.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, typename OutT, int MI, int NPRE, bool FULL = false, int RES = -1, bool EMIT = false>
+// `hook` runs once, after the epilogue's own up-front loads (bias) have been waited for and before its first store: the
+// persistent 256x256 kernel issues the NEXT tile's first K-tile DMA there, so that no compiler-inserted wait for a load of
+// this epilogue can drain that DMA.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+template <int EPI, typename OutT, int MI, int NPRE, bool FULL = false, int RES = -1, bool EMIT = false, typename Hook = NoHook>
 __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][4], unsigned char* eraw, int mwave,
-                                              int nw, int lane, const float4 (&rpre)[NPRE]) {
+                                              int nw, int lane, const float4 (&rpre)[NPRE], Hook hook = Hook()) {
     constexpr int CPL = 16 / (int)sizeof(OutT);                    // columns per lane per store (16 B)
     constexpr int LPR = 64 / CPL, RPI = 64 / LPR, ITERS = 16 / RPI;
     const int l15 = lane & 15, g = lane >> 4;
@@ -173,6 +178,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
         // V part: 64-token x 64-d blocks are transposed through LDS as OutT so that V^T[b,h,d,:] rows are written
         // 128 B (bf16) at a time; Q and K take the generic 16-row path below.
         if (p.kinds[nw / p.inner] == PMHIP_PART_V) {
+            hook();
             const int h = (nw % p.inner) >> 6;
             OutT* dst = reinterpret_cast<OutT*>(p.outs[nw / p.inner]);
 #pragma unroll
@@ -252,6 +258,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
     // clears), and because vmcnt counts stores too, every 16-row slice then waits for the previous slice's stores
     // to be acknowledged by L2 instead of streaming them.
     __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0); expcnt / lgkmcnt untouched
+    hook();
     constexpr bool PIPE_RES = (EPI == EPI_STD) && FULL && RES == 1 && NPRE == 1 && sizeof(OutT) == 4;
     float4 rnext[ITERS] = {};
     if constexpr (PIPE_RES) {
