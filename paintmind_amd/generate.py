@@ -93,13 +93,24 @@ class Pipeline(nn.Module):
         return self._pm_dtype
 
     def engine(self):
+        """native stage-2 handle for the current compute dtype; one cached per dtype, rebuilt when a parameter's
+        (data_ptr, version) changes.  After edits through `p.data` call invalidate_engines()."""
         dtype = self.compute_dtype
         cb = self.vqgan.quantize.embedding.weight
         stamp = (packing.params_fingerprint(self.transformer), cb.data_ptr(), cb._version, self.mask_token.data_ptr(),
-                 self.mask_token._version, dtype)
-        if self._engine is None or self._engine[0] != stamp:
-            self._engine = (stamp, S2Engine(self.transformer, cb, self.mask_token, dtype))
-        return self._engine[1]
+                 self.mask_token._version)
+        cache = self._engine if isinstance(self._engine, dict) else {}
+        hit = cache.get(dtype)
+        if hit is None or hit[0] != stamp:
+            cache[dtype] = hit = (stamp, S2Engine(self.transformer, cb, self.mask_token, dtype))
+            self._engine = cache
+        return hit[1]
+
+    def invalidate_engines(self):
+        """drop every packed weight copy / captured graph of this pipeline and its VQGAN"""
+        self._engine = None
+        self._lane_cache = None
+        self.vqgan.invalidate_engines()
 
     def from_pretrained(self, path):
         return self.load_state_dict(torch.load(path, map_location="cpu"))

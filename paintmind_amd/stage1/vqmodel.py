@@ -36,11 +36,22 @@ class VQModel(nn.Module):
         return self._pm_dtype
 
     def engine(self):
+        """native handle for the current compute dtype.  One engine is cached PER dtype (entering / leaving
+        torch.autocast switches between two live engines instead of re-packing), keyed by a fingerprint of the
+        parameters (data_ptr, version, dtype): load_state_dict, .to() and in-place edits of a Parameter rebuild it.
+        Edits made through `p.data` bypass the version counter: call invalidate_engines() after those."""
         dtype = self.compute_dtype
-        stamp = (packing.params_fingerprint(self), dtype)
-        if self._engine is None or self._engine[0] != stamp:
-            self._engine = (stamp, VqganEngine(self, dtype))
-        return self._engine[1]
+        stamp = packing.params_fingerprint(self)
+        cache = self._engine if isinstance(self._engine, dict) else {}
+        hit = cache.get(dtype)
+        if hit is None or hit[0] != stamp:
+            cache[dtype] = hit = (stamp, VqganEngine(self, dtype))
+            self._engine = cache
+        return hit[1]
+
+    def invalidate_engines(self):
+        """drop the packed weight copies (and their captured graphs); the next call re-packs from the parameters"""
+        self._engine = None
 
     # -- reference API ------------------------------------------------------------------------------
     def freeze(self):

@@ -166,6 +166,28 @@ def test_generate_hipgraph_replay_is_bit_identical(tiny_pipe):
     assert all(torch.equal(x, y) and torch.equal(x, z) for x, y, z in zip(a, b, c))
 
 
+def test_engine_cache_per_dtype_and_invalidate(tiny_vq):
+    """one packed engine per compute dtype (autocast flips between two live engines); Parameter edits are seen through
+    the version counter, edits through .data need invalidate_engines()"""
+    m, p, d = tiny_vq
+    x = t(d["x"])
+    e32 = m.engine()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        e16 = m.engine()
+        assert e16 is not e32 and e16.dtype == torch.bfloat16
+    assert m.engine() is e32                                     # leaving autocast did not rebuild anything
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert m.engine() is e16
+    idx0 = m.encode(x)[2].clone()
+    with torch.no_grad():
+        m.prev_quant.weight.mul_(-1.0)                           # in-place on the Parameter: version bump -> re-pack
+    assert m.engine() is not e32 and not torch.equal(m.encode(x)[2], idx0)
+    m.prev_quant.weight.data.mul_(-1.0)                          # through .data: invisible to the fingerprint
+    stale = m.encode(x)[2]
+    m.invalidate_engines()
+    assert torch.equal(m.encode(x)[2], idx0) and not torch.equal(stale, idx0)
+
+
 def test_hipgraph_survives_workspace_growth(tiny_pipe):
     """A captured decode loop holds raw workspace pointers.  A later, larger call (bigger batch, longer context, a direct
     decode on the shared vqgan handle) reallocates those buffers; the next replay of the small graph must notice and
@@ -176,8 +198,7 @@ def test_hipgraph_survives_workspace_growth(tiny_pipe):
     eager_small = pipe.generate(small, seed=21, **kw)
     eager_big = pipe.generate(big, seed=22, **kw)
     # a fresh engine pair so that the growth really happens after the capture
-    pipe._engine = None
-    pipe.vqgan._engine = None
+    pipe.invalidate_engines()
     for _ in range(3):                                        # eager warm-up, capture, replay
         got = pipe.generate(small, seed=21, use_graph=True, **kw)
     assert torch.equal(got[1], eager_small[1])
