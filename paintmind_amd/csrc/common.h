@@ -156,6 +156,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
     return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, true));
 }
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) {
+    return (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xf, 0xf, true);
+}
+// value held by the OTHER row pair member (lane ^ 16) / the other half (lane ^ 32): for symmetric butterflies
+__device__ __forceinline__ unsigned other16(unsigned v, int lane) {
+    auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);       // a[0] = {row0,row0,row2,row2}, a[1] = {row1,row1,row3,row3}
+    return (lane & 16) ? a[0] : a[1];
+}
+__device__ __forceinline__ unsigned other32(unsigned v, int lane) {
+    auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false);       // a[0] = {lo,lo}, a[1] = {hi,hi}
+    return (lane & 32) ? a[0] : a[1];
+}
 __device__ __forceinline__ float swap16(float v) {   // value of lane ^ 16
     auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float((threadIdx.x & 16) ? a[1] : a[0]);

@@ -23,13 +23,18 @@ __device__ __forceinline__ bool before(float av, int ai, float bv, int bi) {
     return (av > bv) || (av == bv && ai < bi);
 }
 
+// wave-wide arg-max under `before`: a butterfly on the VALU only (DPP inside a row of 16 lanes, then the row / half swaps;
+// nothing goes through the LDS pipe -- DESIGN.md section 4a).  Every lane ends with the same winner: the order is total.
 __device__ __forceinline__ Cand wave_best(Cand c) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(c.v, o, 64);
-        const int oi = __shfl_xor(c.i, o, 64);
-        if (before(ov, oi, c.v, c.i)) { c.v = ov; c.i = oi; }
-    }
+    const int lane = threadIdx.x & 63;
+#define PM_STEP(OV, OI) { const float ov = (OV); const int oi = (OI); if (before(ov, oi, c.v, c.i)) { c.v = ov; c.i = oi; } }
+    PM_STEP(dpp_mov<0xB1>(c.v), dpp_mov<0xB1>(c.i))            // lane ^ 1
+    PM_STEP(dpp_mov<0x4E>(c.v), dpp_mov<0x4E>(c.i))            // lane ^ 2
+    PM_STEP(dpp_mov<0x141>(c.v), dpp_mov<0x141>(c.i))          // the other quad of the half row (quads are uniform now)
+    PM_STEP(dpp_mov<0x140>(c.v), dpp_mov<0x140>(c.i))          // the other half row
+    PM_STEP(__uint_as_float(other16(__float_as_uint(c.v), lane)), (int)other16((unsigned)c.i, lane))
+    PM_STEP(__uint_as_float(other32(__float_as_uint(c.v), lane)), (int)other32((unsigned)c.i, lane))
+#undef PM_STEP
     return c;
 }
 
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(THREADS) void sample_rows_kernel(
                 }
             }
         }
-        col = __shfl(col, wl, 64);
+        col = __builtin_amdgcn_readlane(col, wl);                         // wl is wave-uniform
         if (lane == r) { mine.v = c.v; mine.i = col; }
     }
     // ---- gumbel arg-max among the candidates (lane r evaluates candidate r)
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(THREADS) void sample_rows_kernel(
     const Cand win = wave_best(pert);
     const unsigned long long owner = __ballot(lane < topk && mine.i == win.i);
     const int src = owner ? __ffsll((long long)owner) - 1 : 0;
-    const float raw = __shfl(mine.v, src, 64);
+    const float raw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mine.v), src));   // src is wave-uniform
 
     if (lane == 0) {
         const int64_t pred = win.i;

@@ -182,10 +182,23 @@ def test_engine_cache_per_dtype_and_invalidate(tiny_vq):
     with torch.no_grad():
         m.prev_quant.weight.mul_(-1.0)                           # in-place on the Parameter: version bump -> re-pack
     assert m.engine() is not e32 and not torch.equal(m.encode(x)[2], idx0)
-    m.prev_quant.weight.data.mul_(-1.0)                          # through .data: invisible to the fingerprint
-    stale = m.encode(x)[2]
-    m.invalidate_engines()
-    assert torch.equal(m.encode(x)[2], idx0) and not torch.equal(stale, idx0)
+    with torch.no_grad():
+        m.prev_quant.weight.mul_(-1.0)
+    assert torch.equal(m.encode(x)[2], idx0)
+    # edits through .data are invisible to the fingerprint: a bf16 engine keeps serving its packed (converted) copy
+    # until invalidate_engines() (an fp32 engine aliases the parameter storage, so it sees them at once)
+    m.set_compute_dtype(torch.bfloat16)
+    try:
+        b0 = m.encode(x)[2].clone()
+        m.prev_quant.weight.data.mul_(-1.0)
+        assert torch.equal(m.encode(x)[2], b0)                   # stale packed copy
+        m.invalidate_engines()
+        assert not torch.equal(m.encode(x)[2], b0)
+        m.prev_quant.weight.data.mul_(-1.0)
+        m.invalidate_engines()
+        assert torch.equal(m.encode(x)[2], b0)
+    finally:
+        m.set_compute_dtype(torch.float32)
 
 
 def test_hipgraph_survives_workspace_growth(tiny_pipe):
