@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PMHIP_ABI_VERSION 2
+#define PMHIP_ABI_VERSION 3
 
 enum { PMHIP_OK = 0, PMHIP_EINVAL = 1, PMHIP_EHIP = 2, PMHIP_ENOMEM = 3, PMHIP_ESTATE = 4 };
 enum { PMHIP_F32 = 0, PMHIP_BF16 = 1 };
@@ -108,6 +108,19 @@ int pmhip_lnfold_supported(int dtype, int epi_kind, int M, int N, int K);
 int pmhip_attention(int dtype, const void* Q, const void* K, const void* Vt, void* out, int ldo,
                     int B, int heads, int Nq, int Nkv, int Nkv_pad, int use_exp2,
                     pmhip_stream stream);
+
+/* ---- any dim_head (modules/attention.py:27-33: inner_dim = dim_head * heads, scale = dim_head^-0.5).  The reference's
+ * configs all use 64 and the tuned kernels above are built for it; these entry points forward to them when
+ * dim_head == 64 and otherwise take a plain path: dim_head a multiple of 16 up to 128, heads*dim_head a multiple of 64.
+ *   pmhip_gemm_heads_dh : the projection runs as an ordinary GEMM into `scratch` (f32 [M, nparts*heads*dim_head], caller
+ *                         owned, unused when dim_head == 64) and a split kernel writes Q [B,H,tokens,dh] (* q_scale),
+ *                         K [B,H,tokens_pad,dh] and V^T [B,H,dh,tokens_pad], rounding to `dtype` once.
+ *   pmhip_attention_dh  : flash-style online softmax on the vector ALU, 4 lanes per query row. */
+int pmhip_gemm_heads_dh(int dtype, const void* A, int lda, const void* W, int ldw, int M, int K, int heads, int dim_head,
+                        int tokens, int tokens_pad, int nparts, const int* part_kinds_host,
+                        void* const* part_outs_host, float q_scale, float* scratch, pmhip_stream stream);
+int pmhip_attention_dh(int dtype, const void* Q, const void* K, const void* Vt, void* out, int ldo, int B, int heads,
+                       int dim_head, int Nq, int Nkv, int Nkv_pad, int use_exp2, pmhip_stream stream);
 
 /* torch.nn.LayerNorm over the last dim, eps inside the sqrt (stage1/layers.py:49,51,89,128;
  * stage2/transformer.py:37,39,41,62).  x fp32 [M,D] -> out (`out_dtype`). */
@@ -209,7 +222,8 @@ typedef struct pmhip_layer_weights {
 } pmhip_layer_weights;
 
 typedef struct pmhip_tower_cfg {
-    int dim, depth, heads, hidden_pad;         /* dim_head is fixed at 64                       */
+    int dim, depth, heads, hidden_pad;
+    int dim_head;                              /* 0 means 64 (the reference's configs); see pmhip_attention_dh */
 } pmhip_tower_cfg;
 
 typedef struct pmhip_vqgan_cfg {

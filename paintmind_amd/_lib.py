@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpaintmind_hip.so")
 PMHIP_OK = 0
 F32, BF16 = 0, 1
 PART_Q, PART_K, PART_V = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 vp = C.c_void_p
 i32 = C.c_int
@@ -31,7 +31,7 @@ class LayerWeights(C.Structure):
 
 
 class TowerCfg(C.Structure):
-    _fields_ = [("dim", i32), ("depth", i32), ("heads", i32), ("hidden_pad", i32)]
+    _fields_ = [("dim", i32), ("depth", i32), ("heads", i32), ("hidden_pad", i32), ("dim_head", i32)]
 
 
 class VqganCfg(C.Structure):
@@ -79,6 +79,9 @@ PROTOTYPES = {
                                   C.POINTER(vp), f32, C.POINTER(LnFold), vp]),
     "pmhip_lnfold_supported": (i32, [i32, i32, i32, i32, i32]),
     "pmhip_attention": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "pmhip_gemm_heads_dh": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32),
+                                  C.POINTER(vp), f32, vp, vp]),
+    "pmhip_attention_dh": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "pmhip_layernorm": (i32, [vp, vp, vp, f32, vp, i32, i32, i32, vp]),
     "pmhip_patchify": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "pmhip_unpatchify_clamp": (i32, [vp, vp, i32, i32, i32, i32, i32, f32, f32, vp]),

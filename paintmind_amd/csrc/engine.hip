@@ -145,6 +145,7 @@ struct TowerBufs {
     void* q = nullptr; void* k = nullptr; void* vt = nullptr;
     void* attn = nullptr;   // T [M, inner]
     void* hid = nullptr;    // T [M, hidden_pad]
+    float* split = nullptr; // dim_head != 64 only: f32 scratch of the plain head-split path [M, 3*inner]
     float* stats = nullptr; // LayerNorm fold: per row and 64-column chunk (sum x, sum x^2) of the residual stream
     // LayerNorm fold state of one forward pass.  fold: the handle is in bf16 mode and folding is enabled; stats_valid:
     // `stats` and the bf16 copy of x (kept in `y`) describe the CURRENT x (its producer was a GEMM that emitted them)
@@ -154,6 +155,15 @@ struct TowerBufs {
 // The LayerNorm fold is OPT-IN (PMHIP_LN_FOLD=1, read on every forward so that tests can switch it): it removes the
 // LayerNorm launches (432 -> 8 per bench step) but costs the consumer GEMMs ~1-2 us per tile, and with three concurrent
 // lanes the HBM-bound LayerNorm already hides under the other lanes' GEMMs: measured 401 vs 410 images/s.
+inline int dh_of(const pmhip_tower_cfg& tc) { return tc.dim_head > 0 ? tc.dim_head : 64; }
+
+int check_dim_head(const char* who, const pmhip_tower_cfg& tc) {
+    const int dh = dh_of(tc);
+    PM_REQUIRE(tc.heads > 0 && dh >= 16 && dh <= 128 && dh % 16 == 0 && (tc.heads * dh) % 64 == 0,
+               "%s: heads=%d dim_head=%d: dim_head must be a multiple of 16 in [16,128] and heads*dim_head a multiple of 64", who, tc.heads, dh);
+    return PMHIP_OK;
+}
+
 bool ln_fold_enabled() {
     const char* e = getenv("PMHIP_LN_FOLD");
     return e && atoi(e) != 0;
@@ -163,17 +173,19 @@ int alloc_tower(Workspace& ws, const char* tag, int dtype, const pmhip_tower_cfg
                 hipStream_t s) {
     const size_t es = dtype_size(dtype);
     const size_t M = (size_t)B * tokens;
-    const int inner = tc.heads * 64, Np = round_up(tokens, 64);
+    const int dh = dh_of(tc), inner = tc.heads * dh, Np = round_up(tokens, 64);
     std::string t(tag);
     WS(ws, (t + ".x").c_str(), M * tc.dim * 4, b.x);
     WS(ws, (t + ".y").c_str(), M * tc.dim * es, b.y);
-    WS(ws, (t + ".q").c_str(), (size_t)B * tc.heads * tokens * 64 * es, b.q);
-    WS(ws, (t + ".k").c_str(), (size_t)B * tc.heads * Np * 64 * es, b.k);
-    WS(ws, (t + ".vt").c_str(), (size_t)B * tc.heads * Np * 64 * es, b.vt);
+    WS(ws, (t + ".q").c_str(), (size_t)B * tc.heads * tokens * dh * es, b.q);
+    WS(ws, (t + ".k").c_str(), (size_t)B * tc.heads * Np * dh * es, b.k);
+    WS(ws, (t + ".vt").c_str(), (size_t)B * tc.heads * Np * dh * es, b.vt);
     WS(ws, (t + ".attn").c_str(), M * inner * es, b.attn);
     WS(ws, (t + ".hid").c_str(), M * tc.hidden_pad * es, b.hid);
     WS(ws, (t + ".stats").c_str(), M * (tc.dim / 64) * 2 * 4, b.stats);
-    b.fold = dtype == PMHIP_BF16 && ln_fold_enabled();
+    b.split = nullptr;
+    if (dh != 64) WS(ws, (t + ".split").c_str(), M * 3 * inner * 4, b.split);
+    b.fold = dtype == PMHIP_BF16 && dh == 64 && ln_fold_enabled();
     b.stats_valid = false;
     return PMHIP_OK;
 }
@@ -193,32 +205,34 @@ int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W
 
 // LN(x) -> head-split projection: folded when the statistics of x are at hand and the shape is served, else LayerNorm + GEMM
 int ln_heads(int dtype, TowerBufs& b, const float* g, const float* be, const void* W, const void* Wf, const float* fc, const float* fd,
-             int M, int dim, int heads, int tokens, int Np, int nparts, const int* kinds, void* const* outs, float q_scale, hipStream_t s) {
+             int M, int dim, int heads, int dh, int tokens, int Np, int nparts, const int* kinds, void* const* outs, float q_scale,
+             hipStream_t s) {
     if (b.fold && b.stats_valid && Wf && pmhip_lnfold_supported(dtype, 2, M, nparts * heads * 64, dim)) {
         const pmhip_lnfold ln{b.stats, fc, fd, 1e-5f};
         return pmhip_gemm_heads_ln(dtype, b.y, dim, Wf, dim, M, dim, heads, tokens, Np, nparts, kinds, outs, q_scale, &ln, s);
     }
     PM_TRY(pmhip_layernorm(b.x, g, be, 1e-5f, b.y, dtype, M, dim, s));
     b.stats_valid = false;                                     // b.y now holds LN(x), not bf16(x)
-    return pmhip_gemm_heads(dtype, b.y, dim, W, dim, M, dim, heads, tokens, Np, nparts, kinds, outs, q_scale, s);
+    return pmhip_gemm_heads_dh(dtype, b.y, dim, W, dim, M, dim, heads, dh, tokens, Np, nparts, kinds, outs, q_scale, b.split, s);
 }
 
 // one pre-LN transformer block (stage1/layers.py:54-58; stage2/transformer.py:44-49)
 int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg& tc, TowerBufs& b, int B, int tokens,
                   bool stage2, const CrossKV* cross, hipStream_t s) {
-    const int M = B * tokens, dim = tc.dim, inner = tc.heads * 64, Np = round_up(tokens, 64);
+    const int dh = dh_of(tc);
+    const int M = B * tokens, dim = tc.dim, inner = tc.heads * dh, Np = round_up(tokens, 64);
     const bool fast = dtype == PMHIP_BF16;
-    const float q_scale = 0.125f * (fast ? kLog2e : 1.0f);      // dim_head^-0.5, attention.py:31,52
+    const float q_scale = (dh == 64 ? 0.125f : 1.0f / sqrtf((float)dh)) * (fast ? kLog2e : 1.0f);   // dim_head^-0.5, attention.py:31,52
     const int kinds_qkv[3] = {PMHIP_PART_Q, PMHIP_PART_K, PMHIP_PART_V};
     const float eps = 1e-5f;
 
     // x = attn1(norm1(x)) + x
     {
         void* outs[3] = {b.q, b.k, b.vt};
-        PM_TRY(ln_heads(dtype, b, L.ln1_g, L.ln1_b, L.wqkv, L.wqkv_f, L.qkv_c, L.qkv_d, M, dim, tc.heads, tokens, Np, 3, kinds_qkv, outs,
+        PM_TRY(ln_heads(dtype, b, L.ln1_g, L.ln1_b, L.wqkv, L.wqkv_f, L.qkv_c, L.qkv_d, M, dim, tc.heads, dh, tokens, Np, 3, kinds_qkv, outs,
                         q_scale, s));
     }
-    PM_TRY(pmhip_attention(dtype, b.q, b.k, b.vt, b.attn, inner, B, tc.heads, tokens, tokens, Np, fast, s));
+    PM_TRY(pmhip_attention_dh(dtype, b.q, b.k, b.vt, b.attn, inner, B, tc.heads, dh, tokens, tokens, Np, fast, s));
     PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo, inner, L.bo, b.x, dim, M, M, dim, inner, s));
 
     if (stage2) {
@@ -226,14 +240,14 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
         if (cross && cross->k) {
             const int kind_q[1] = {PMHIP_PART_Q};
             void* outs[1] = {b.q};
-            PM_TRY(ln_heads(dtype, b, L.lnx_g, L.lnx_b, L.wqkv2, L.wqkv2_f, L.qkv2_c, L.qkv2_d, M, dim, tc.heads, tokens, Np, 1, kind_q,
+            PM_TRY(ln_heads(dtype, b, L.lnx_g, L.lnx_b, L.wqkv2, L.wqkv2_f, L.qkv2_c, L.qkv2_d, M, dim, tc.heads, dh, tokens, Np, 1, kind_q,
                             outs, q_scale, s));
-            PM_TRY(pmhip_attention(dtype, b.q, cross->k, cross->vt, b.attn, inner, B, tc.heads, tokens, cross->L, cross->Lp, fast, s));
+            PM_TRY(pmhip_attention_dh(dtype, b.q, cross->k, cross->vt, b.attn, inner, B, tc.heads, dh, tokens, cross->L, cross->Lp, fast, s));
         } else {
             void* outs[3] = {b.q, b.k, b.vt};
-            PM_TRY(ln_heads(dtype, b, L.lnx_g, L.lnx_b, L.wqkv2, L.wqkv2_f, L.qkv2_c, L.qkv2_d, M, dim, tc.heads, tokens, Np, 3, kinds_qkv,
+            PM_TRY(ln_heads(dtype, b, L.lnx_g, L.lnx_b, L.wqkv2, L.wqkv2_f, L.qkv2_c, L.qkv2_d, M, dim, tc.heads, dh, tokens, Np, 3, kinds_qkv,
                             outs, q_scale, s));
-            PM_TRY(pmhip_attention(dtype, b.q, b.k, b.vt, b.attn, inner, B, tc.heads, tokens, tokens, Np, fast, s));
+            PM_TRY(pmhip_attention_dh(dtype, b.q, b.k, b.vt, b.attn, inner, B, tc.heads, dh, tokens, tokens, Np, fast, s));
         }
         PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo2, inner, L.bo2, b.x, dim, M, M, dim, inner, s));
     }
@@ -276,6 +290,8 @@ extern "C" int pmhip_vqgan_create(pmhip_vqgan** out, int device, int dtype, cons
     PM_REQUIRE(cfg->enc.dim % 64 == 0 && cfg->dec.dim % 64 == 0, "vqgan_create: dim must be a multiple of 64");
     PM_REQUIRE(cfg->enc.hidden_pad % 64 == 0 && cfg->dec.hidden_pad % 64 == 0, "vqgan_create: hidden_pad must be a multiple of 64");
     PM_REQUIRE(cfg->embed_dim <= 64 && cfg->embed_dim % 4 == 0, "vqgan_create: embed_dim must be <= 64 and a multiple of 4");
+    PM_TRY(check_dim_head("vqgan_create(enc)", cfg->enc));
+    PM_TRY(check_dim_head("vqgan_create(dec)", cfg->dec));
     auto h = std::make_unique<pmhip_vqgan>();
     h->device = device; h->dtype = dtype; h->cfg = *cfg; h->w = *w;
     h->enc_layers.assign(w->enc_layers, w->enc_layers + cfg->enc.depth);
@@ -440,6 +456,7 @@ extern "C" int pmhip_s2_create(pmhip_s2** out, int device, int dtype, const pmhi
     PM_REQUIRE(dtype == PMHIP_F32 || dtype == PMHIP_BF16, "s2_create: bad dtype");
     PM_REQUIRE(cfg->tower.dim % 64 == 0 && cfg->tower.hidden_pad % 64 == 0, "s2_create: dim/hidden_pad must be multiples of 64");
     PM_REQUIRE(cfg->embed_dim <= 64 && cfg->embed_dim % 4 == 0, "s2_create: embed_dim must be <= 64 and a multiple of 4");
+    PM_TRY(check_dim_head("s2_create", cfg->tower));
     PM_REQUIRE(cfg->context_dim_pad % 64 == 0 && cfg->context_dim_pad >= cfg->context_dim, "s2_create: bad context_dim_pad");
     PM_REQUIRE(w->ctxproj_w || cfg->context_dim == cfg->tower.dim, "s2_create: Identity context_proj needs context_dim == dim");
     PM_REQUIRE(cfg->n_embed % 4 == 0, "s2_create: n_embed must be a multiple of 4");
@@ -464,7 +481,7 @@ namespace {
 // (attention.py:48-49).  The context is static over a decode loop, so this runs once per loop.
 int s2_prepare_context(pmhip_s2* h, const float* context, int L, int B, hipStream_t s) {
     const auto& c = h->cfg;
-    const int dim = c.tower.dim, heads = c.tower.heads, inner = heads * 64;
+    const int dim = c.tower.dim, heads = c.tower.heads, dh = dh_of(c.tower), inner = heads * dh;
     const size_t es = dtype_size(h->dtype);
     if (!context) {
         for (auto& ck : h->cross) ck = CrossKV{};
@@ -482,14 +499,16 @@ int s2_prepare_context(pmhip_s2* h, const float* context, int L, int B, hipStrea
     } else {
         cp = cT;
     }
-    const size_t per = (size_t)B * heads * Lp * 64 * es;
+    const size_t per = (size_t)B * heads * Lp * dh * es;
     unsigned char* kv;
     WS(h->ws, "ctx.kv", per * 2 * c.tower.depth, kv);
+    float* split = nullptr;
+    if (dh != 64) WS(h->ws, "ctx.split", (size_t)Mc * 2 * inner * 4, split);
     const int kinds[2] = {PMHIP_PART_K, PMHIP_PART_V};
     for (int l = 0; l < c.tower.depth; ++l) {
         void* outs[2] = {kv + per * (2 * l), kv + per * (2 * l + 1)};
         const unsigned char* wkv = reinterpret_cast<const unsigned char*>(h->layers[l].wqkv2) + (size_t)inner * dim * es;
-        PM_TRY(pmhip_gemm_heads(h->dtype, cp, dim, wkv, dim, Mc, dim, heads, L, Lp, 2, kinds, outs, 1.0f, s));
+        PM_TRY(pmhip_gemm_heads_dh(h->dtype, cp, dim, wkv, dim, Mc, dim, heads, dh, L, Lp, 2, kinds, outs, 1.0f, split, s));
         h->cross[l].k = outs[0]; h->cross[l].vt = outs[1]; h->cross[l].L = L; h->cross[l].Lp = Lp;
     }
     return PMHIP_OK;

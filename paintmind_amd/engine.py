@@ -109,8 +109,8 @@ class VqganEngine:
         cfg.n_embed, cfg.embed_dim, cfg.beta = vq.n_e, vq.e_dim, float(vq.beta)
         a_enc = enc.transformer.layers[0].attn1
         a_dec = dec.transformer.layers[0].attn1
-        cfg.enc = TowerCfg(conv.out_channels, len(enc.transformer.layers), a_enc.heads, enc_hp)
-        cfg.dec = TowerCfg(dec.proj.in_features, len(dec.transformer.layers), a_dec.heads, dec_hp)
+        cfg.enc = TowerCfg(conv.out_channels, len(enc.transformer.layers), a_enc.heads, enc_hp, a_enc.dim_head)
+        cfg.dec = TowerCfg(dec.proj.in_features, len(dec.transformer.layers), a_dec.heads, dec_hp, a_dec.dim_head)
         self.cfg, self.weights = cfg, w
         self.handle = C.c_void_p()
         check(self.lib.pmhip_vqgan_create(C.byref(self.handle), dev.index or 0, pm_dtype(dtype), C.byref(cfg), C.byref(w)),
@@ -229,7 +229,7 @@ class S2Engine:
         cfg.embed_dim = tr.token_proj.in_features
         cfg.n_embed = tr.to_logits.out_features
         cfg.context_dim, cfg.context_dim_pad = ctx_dim, ctx_pad
-        cfg.tower = TowerCfg(dim, len(layers), layers[0].attn1.heads, hp)
+        cfg.tower = TowerCfg(dim, len(layers), layers[0].attn1.heads, hp, layers[0].attn1.dim_head)
         self.cfg, self.weights = cfg, w
         self.tokens, self.n_embed, self.embed_dim, self.context_dim = cfg.tokens, cfg.n_embed, cfg.embed_dim, ctx_dim
         self.handle = C.c_void_p()

@@ -20,12 +20,14 @@ XFORMERS_IS_AVAILBLE = False   # name kept for source compatibility (reference a
 class CrossAttention(nn.Module):
     def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.):
         super().__init__()
-        if dim_head != 64:
-            raise ValueError(f"the HIP attention kernel is built for dim_head=64, got {dim_head}")
+        if dim_head % 16 or not 16 <= dim_head <= 128 or (dim_head * heads) % 64:
+            raise ValueError(f"dim_head={dim_head}, heads={heads}: the HIP operators serve dim_head = 16, 32, ..., 128 with "
+                             f"heads*dim_head a multiple of 64 (64 runs the tuned MFMA kernels, the rest a plain path)")
         inner_dim = dim_head * heads
         context_dim = query_dim if context_dim is None else context_dim
         self.scale = dim_head ** -0.5
         self.heads = heads
+        self.dim_head = dim_head
         self.query_dim = query_dim
         self.context_dim = context_dim
         # creation order == the reference's, so a seeded construction draws identical weights
@@ -68,13 +70,13 @@ class CrossAttention(nn.Module):
         if context is None:
             if "wqkv" not in pk:
                 raise ValueError("self-attention needs context_dim == query_dim")
-            q, k, vt = ops.gemm_heads(a, pk["wqkv"], self.heads, N, [ops.PART_Q, ops.PART_K, ops.PART_V], q_scale)
+            q, k, vt = ops.gemm_heads(a, pk["wqkv"], self.heads, N, [ops.PART_Q, ops.PART_K, ops.PART_V], q_scale, self.dim_head)
             n_kv = N
         else:
             L = context.shape[1]
             c = _rows(context.reshape(B * L, context.shape[2]), dtype)
-            (q,) = ops.gemm_heads(a, pk["wq"], self.heads, N, [ops.PART_Q], q_scale)
-            k, vt = ops.gemm_heads(c, pk["wkv"], self.heads, L, [ops.PART_K, ops.PART_V], 1.0)
+            (q,) = ops.gemm_heads(a, pk["wq"], self.heads, N, [ops.PART_Q], q_scale, self.dim_head)
+            k, vt = ops.gemm_heads(c, pk["wkv"], self.heads, L, [ops.PART_K, ops.PART_V], 1.0, self.dim_head)
             n_kv = L
         o = ops.attention(q, k, vt, n_kv, use_exp2=fast)
         res = residual.reshape(B * N, D) if residual is not None else None

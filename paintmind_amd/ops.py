@@ -83,26 +83,34 @@ def gemm_swiglu(a, w12p, b12p):
     return out
 
 
-def gemm_heads(a, w, heads, tokens, kinds, q_scale=1.0):
-    """Head-split projection; returns one tensor per part (Q [B,H,t,64], K [B,H,tp,64], V^T [B,H,64,tp])."""
+def gemm_heads(a, w, heads, tokens, kinds, q_scale=1.0, dim_head=64):
+    """Head-split projection; returns one tensor per part (Q [B,H,t,dh], K [B,H,tp,dh], V^T [B,H,dh,tp]).
+    dim_head 64 runs the fused epilogue; other values the plain GEMM + split path (pmhip_gemm_heads_dh)."""
     dev = _dev(a, w)
     lib = _lib.load()
     M, K = a.shape
     B = M // tokens
     tp = round_up(tokens, 64)
+    dh = int(dim_head)
     outs = []
     for kind in kinds:
         if kind == PART_Q:
-            outs.append(torch.empty(B, heads, tokens, 64, device=dev, dtype=a.dtype))
+            outs.append(torch.empty(B, heads, tokens, dh, device=dev, dtype=a.dtype))
         elif kind == PART_K:
-            outs.append(torch.zeros(B, heads, tp, 64, device=dev, dtype=a.dtype))
+            outs.append(torch.zeros(B, heads, tp, dh, device=dev, dtype=a.dtype))
         else:
-            outs.append(torch.zeros(B, heads, 64, tp, device=dev, dtype=a.dtype))
+            outs.append(torch.zeros(B, heads, dh, tp, device=dev, dtype=a.dtype))
     kinds_c = (C.c_int * len(kinds))(*kinds)
     outs_c = (C.c_void_p * len(kinds))(*[o.data_ptr() for o in outs])
     with torch.cuda.device(dev):
-        check(lib.pmhip_gemm_heads(pm_dtype(a.dtype), _p(a), a.stride(0), _p(w), w.stride(0), M, K, heads, tokens, tp,
-                                   len(kinds), kinds_c, outs_c, float(q_scale), stream_ptr(dev)), "pmhip_gemm_heads")
+        if dh == 64:
+            check(lib.pmhip_gemm_heads(pm_dtype(a.dtype), _p(a), a.stride(0), _p(w), w.stride(0), M, K, heads, tokens, tp,
+                                       len(kinds), kinds_c, outs_c, float(q_scale), stream_ptr(dev)), "pmhip_gemm_heads")
+        else:
+            scratch = torch.empty(M, len(kinds) * heads * dh, device=dev, dtype=torch.float32)
+            check(lib.pmhip_gemm_heads_dh(pm_dtype(a.dtype), _p(a), a.stride(0), _p(w), w.stride(0), M, K, heads, dh, tokens, tp,
+                                          len(kinds), kinds_c, outs_c, float(q_scale), _p(scratch), stream_ptr(dev)),
+                  "pmhip_gemm_heads_dh")
     return outs
 
 
@@ -182,15 +190,19 @@ def gemm_heads_ln(xb, wg, heads, tokens, kinds, q_scale, stats, c, d, eps=1e-5):
 
 
 def attention(q, k, vt, n_kv, use_exp2=False):
-    """q [B,H,Nq,64], k [B,H,Nkp,64], vt [B,H,64,Nkp] -> [B*Nq, H*64]."""
+    """q [B,H,Nq,dh], k [B,H,Nkp,dh], vt [B,H,dh,Nkp] -> [B*Nq, H*dh]  (dh 64: tuned MFMA kernel; else pmhip_attention_dh)."""
     dev = _dev(q, k, vt)
     lib = _lib.load()
-    B, H, Nq, _ = q.shape
+    B, H, Nq, dh = q.shape
     nkp = k.shape[2]
-    out = torch.empty(B * Nq, H * 64, device=dev, dtype=q.dtype)
+    out = torch.empty(B * Nq, H * dh, device=dev, dtype=q.dtype)
     with torch.cuda.device(dev):
-        check(lib.pmhip_attention(pm_dtype(q.dtype), _p(q), _p(k), _p(vt), _p(out), H * 64, B, H, Nq, n_kv, nkp,
-                                  int(use_exp2), stream_ptr(dev)), "pmhip_attention")
+        if dh == 64:
+            check(lib.pmhip_attention(pm_dtype(q.dtype), _p(q), _p(k), _p(vt), _p(out), H * 64, B, H, Nq, n_kv, nkp,
+                                      int(use_exp2), stream_ptr(dev)), "pmhip_attention")
+        else:
+            check(lib.pmhip_attention_dh(pm_dtype(q.dtype), _p(q), _p(k), _p(vt), _p(out), H * dh, B, H, dh, Nq, n_kv, nkp,
+                                         int(use_exp2), stream_ptr(dev)), "pmhip_attention_dh")
     return out
 
 
