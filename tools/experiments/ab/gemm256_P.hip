@@ -43,33 +43,28 @@ __device__ __forceinline__ int piece_row(int piece, int c) {
     return grp * 64 + within + (piece == PW1 ? 32 : 0);
 }
 
-// A piece = 16 chunks of 8 rows; wave w DMAs chunks 2w, 2w+1 with `buffer_load_dwordx4 ... lds`: the operand's tile origin
-// is the base of a buffer descriptor (SGPRs), the chunk row and the k offset form the scalar offset, and ONE per-lane byte
-// offset per operand (row-in-chunk * ld + swizzled 16-B slot) is the vector offset -- a DMA instruction costs its wave
-// two SALU operations and no VALU (the flat global_load_lds form needed a 64-bit VALU add per instruction, issued by the
-// read-slot wave while its SIMD partner holds priority for MFMAs).
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t tile_rsrc(const void* origin) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(origin), 0, 0x7fffffff, 0x00020000);   // raw buffer, no bounds in play
-}
-__device__ __forceinline__ void issue_piece(int piece, rsrc_t Ar, rsrc_t Wr, unsigned lda_b, unsigned ldw_b, unsigned laneoffA,
-                                            unsigned laneoffW, int k0, unsigned char* buf, int wave, int i0 = 0, int i1 = 2) {
+// A piece = 16 chunks of 8 rows; wave w DMAs chunks 2w, 2w+1.  The source address splits into a wave-uniform
+// part (operand base, tile origin, chunk row, k offset: SGPRs) and ONE per-lane byte offset per operand
+// (row-in-chunk * ld + swizzled 16-B slot), so no per-piece address VGPRs are kept alive.
+__device__ __forceinline__ void issue_piece(int piece, const unsigned char* __restrict__ Ab, const unsigned char* __restrict__ Wb,
+                                            size_t lda_b, size_t ldw_b, unsigned laneoffA, unsigned laneoffW, int k0,
+                                            unsigned char* buf, int wave, int i0 = 0, int i1 = 2) {
     const bool isA = (piece == PA0 || piece == PA1);
-    const unsigned ld_b = isA ? lda_b : ldw_b;
+    const unsigned char* base = isA ? Ab : Wb;                     // already offset to the tile origin row
+    const size_t ld_b = isA ? lda_b : ldw_b;
     const unsigned laneoff = isA ? laneoffA : laneoffW;
     unsigned char* tile = buf + (isA ? 0 : OPER_BYTES);
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
         const int row0 = piece_row(piece, wave * 2 + i);           // wave-uniform
-        const unsigned soff = (unsigned)row0 * ld_b + (unsigned)k0 * 2u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? Ar : Wr, (__attribute__((address_space(3))) void*)(tile + row0 * ROWB), 16, laneoff,
-                                                 soff, 0, 0);
+        const unsigned char* sbase = base + (size_t)row0 * ld_b + (size_t)k0 * 2;
+        glds16(sbase + laneoff, tile + row0 * ROWB);
     }
 }
 
 struct LoopCtx {
-    rsrc_t Ar, Wr;                                      // buffer descriptors based at the tile origin rows of A / W
-    unsigned lda_b, ldw_b;
+    const unsigned char* Ab; const unsigned char* Wb;   // operand bases at the tile origin rows
+    size_t lda_b, ldw_b;
     unsigned laneoffA, laneoffW;                        // per-lane DMA source offsets
     unsigned fa0, fa1, fw0, fw1;                        // per-lane fragment read offsets (kk = 0, 1)
     unsigned lds_base;                                  // LDS byte address of the staging buffers
@@ -102,7 +97,7 @@ struct LoopCtx {
 #define LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
 #define BAR __builtin_amdgcn_s_barrier()
 #define ISSUE(piece) \
-    if constexpr (HAS_NEXT) issue_piece(piece, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, (kt + 1) * KSTEP, nxt, c.wave);
+    if constexpr (HAS_NEXT) issue_piece(piece, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, (kt + 1) * KSTEP, nxt, c.wave);
 #define WAIT(last_n)                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     if constexpr (HAS_NEXT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                     \
@@ -193,7 +188,7 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     const int ntiles = (p.M / BM) * (p.N / BN);
     const int tiles_m = p.M / BM, tiles_n = p.N / BN;
     LoopCtx c;
-    c.lda_b = (unsigned)p.lda * 2u; c.ldw_b = (unsigned)p.ldw * 2u;
+    c.lda_b = (size_t)p.lda * 2; c.ldw_b = (size_t)p.ldw * 2;
     const unsigned lswz = (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);       // chunk rows start at multiples of 8
     c.laneoffA = (unsigned)(lane >> 3) * (unsigned)c.lda_b + lswz;
     c.laneoffW = (unsigned)(lane >> 3) * (unsigned)c.ldw_b + lswz;
@@ -214,16 +209,16 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     };
     int tile = blockIdx.x, m0, n0;
     origin(tile, m0, n0);
-    c.Ar = tile_rsrc(reinterpret_cast<const unsigned char*>(p.A) + (size_t)m0 * c.lda_b);
-    c.Wr = tile_rsrc(reinterpret_cast<const unsigned char*>(p.W) + (size_t)n0 * c.ldw_b);
+    c.Ab = reinterpret_cast<const unsigned char*>(p.A) + (size_t)m0 * c.lda_b;
+    c.Wb = reinterpret_cast<const unsigned char*>(p.W) + (size_t)n0 * c.ldw_b;
 
     // prologue of the FIRST tile: its whole first K-tile, in need-order; PA0 + PW0 must have landed before phase 1
     LnLoads lnl;
     if constexpr (FOLD) ln_stats_issue(p, m0 + wm * 128, n0 + wn * 64, lane, lnl);      // before the DMA: these return first
-    issue_piece(PA0, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
-    issue_piece(PW0, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
-    issue_piece(PW1, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
-    issue_piece(PA1, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PA0, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PW0, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PW1, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PA1, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     float fa[FOLD ? 8 : 1], fb[FOLD ? 8 : 1];
     float* fscr = reinterpret_cast<float*>(lds + 2 * BUF_BYTES + (FOLD ? wave * 2048 : 0));
     if constexpr (FOLD) ln_row_coeffs<8>(p, lane, fscr, lnl, fa, fb);        // 4 pieces x 2 DMA instructions stay in flight
@@ -246,15 +241,15 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
         const bool has_next = next < ntiles;
         int m1 = 0, n1 = 0;
         if (has_next) origin(next, m1, n1);
-        const rsrc_t Ar1 = tile_rsrc(reinterpret_cast<const unsigned char*>(p.A) + (size_t)m1 * c.lda_b);
-        const rsrc_t Wr1 = tile_rsrc(reinterpret_cast<const unsigned char*>(p.W) + (size_t)n1 * c.ldw_b);
+        const unsigned char* Ab1 = reinterpret_cast<const unsigned char*>(p.A) + (size_t)m1 * c.lda_b;
+        const unsigned char* Wb1 = reinterpret_cast<const unsigned char*>(p.W) + (size_t)n1 * c.ldw_b;
         auto prefetch = [&]() {
             if (has_next) {
                 unsigned char* b1 = lds + BUF_BYTES;
-                issue_piece(PA0, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
-                issue_piece(PW0, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
-                issue_piece(PW1, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
-                issue_piece(PA1, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+                issue_piece(PA0, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+                issue_piece(PW0, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+                issue_piece(PW1, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+                issue_piece(PA1, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
             }
         };
         if constexpr (FOLD) ln_apply<8>(fscr, acc, lane, fa, fb);
@@ -276,7 +271,7 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // every wave is done staging through buffer 0; the K-tile is visible
         tile = next; m0 = m1; n0 = n1;
-        c.Ar = Ar1; c.Wr = Wr1;
+        c.Ab = Ab1; c.Wb = Wb1;
         pb = 1;
     }
 }

@@ -1,3 +1,5 @@
+#define ABL_NOBAR 1
+#define ABL_NODMA 1
 // 256x256 phase-staggered bf16 NT GEMM for gfx950 (the large-shape member of the family in gemm.hip).
 //
 // Geometry: 512 threads = 8 waves as 2(m) x 4(n); a wave owns 128 x 64 of the output = acc[8][4] MFMA tiles
@@ -23,6 +25,15 @@
 
 #include "gemm_common.h"
 
+#ifndef ABL_NODMA
+#define ABL_NODMA 0
+#endif
+#ifndef ABL_NOREAD
+#define ABL_NOREAD 0
+#endif
+#ifndef ABL_NOBAR
+#define ABL_NOBAR 0
+#endif
 using namespace pmgemm;
 
 namespace {
@@ -43,45 +54,49 @@ __device__ __forceinline__ int piece_row(int piece, int c) {
     return grp * 64 + within + (piece == PW1 ? 32 : 0);
 }
 
-// A piece = 16 chunks of 8 rows; wave w DMAs chunks 2w, 2w+1 with `buffer_load_dwordx4 ... lds`: the operand's tile origin
-// is the base of a buffer descriptor (SGPRs), the chunk row and the k offset form the scalar offset, and ONE per-lane byte
-// offset per operand (row-in-chunk * ld + swizzled 16-B slot) is the vector offset -- a DMA instruction costs its wave
-// two SALU operations and no VALU (the flat global_load_lds form needed a 64-bit VALU add per instruction, issued by the
-// read-slot wave while its SIMD partner holds priority for MFMAs).
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t tile_rsrc(const void* origin) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(origin), 0, 0x7fffffff, 0x00020000);   // raw buffer, no bounds in play
-}
-__device__ __forceinline__ void issue_piece(int piece, rsrc_t Ar, rsrc_t Wr, unsigned lda_b, unsigned ldw_b, unsigned laneoffA,
-                                            unsigned laneoffW, int k0, unsigned char* buf, int wave, int i0 = 0, int i1 = 2) {
+// A piece = 16 chunks of 8 rows; wave w DMAs chunks 2w, 2w+1.  The source address splits into a wave-uniform
+// part (operand base, tile origin, chunk row, k offset: SGPRs) and ONE per-lane byte offset per operand
+// (row-in-chunk * ld + swizzled 16-B slot), so no per-piece address VGPRs are kept alive.
+__device__ __forceinline__ void issue_piece(int piece, const unsigned char* __restrict__ Ab, const unsigned char* __restrict__ Wb,
+                                            size_t lda_b, size_t ldw_b, unsigned laneoffA, unsigned laneoffW, int k0,
+                                            unsigned char* buf, int wave, int i0 = 0, int i1 = 2) {
     const bool isA = (piece == PA0 || piece == PA1);
-    const unsigned ld_b = isA ? lda_b : ldw_b;
+    const unsigned char* base = isA ? Ab : Wb;                     // already offset to the tile origin row
+    const size_t ld_b = isA ? lda_b : ldw_b;
     const unsigned laneoff = isA ? laneoffA : laneoffW;
     unsigned char* tile = buf + (isA ? 0 : OPER_BYTES);
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
         const int row0 = piece_row(piece, wave * 2 + i);           // wave-uniform
-        const unsigned soff = (unsigned)row0 * ld_b + (unsigned)k0 * 2u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? Ar : Wr, (__attribute__((address_space(3))) void*)(tile + row0 * ROWB), 16, laneoff,
-                                                 soff, 0, 0);
+        const unsigned char* sbase = base + (size_t)row0 * ld_b + (size_t)k0 * 2;
+        glds16(sbase + laneoff, tile + row0 * ROWB);
     }
 }
 
 struct LoopCtx {
-    rsrc_t Ar, Wr;                                      // buffer descriptors based at the tile origin rows of A / W
-    unsigned lda_b, ldw_b;
+    const unsigned char* Ab; const unsigned char* Wb;   // operand bases at the tile origin rows
+    size_t lda_b, ldw_b;
     unsigned laneoffA, laneoffW;                        // per-lane DMA source offsets
     unsigned fa0, fa1, fw0, fw1;                        // per-lane fragment read offsets (kk = 0, 1)
     unsigned lds_base;                                  // LDS byte address of the staging buffers
     int nk, wave;
 };
 
-
-// Fragment reads are inline-asm ds_read_b128: hipcc would otherwise put `s_waitcnt vmcnt(0)` in front of every
-// LDS read while a DMA (an LDS write on the VM counter) is in flight and drain the pipeline each phase.  The
-// counted waits + barriers below are what orders a read after the DMA that produced its data.  Offsets are
-// literal immediates (the "n" constraint needs constants, hence the macro expansion).
+// The K loop for one wave.  LEAD = true: waves with wm = 0 ({reads | MFMAs}); LEAD = false: waves with wm = 1, one
+// slot behind ({MFMAs of the previous phase | reads}).  Both versions execute the SAME sequence of barriers, DMA
+// issues and vmcnt waits; they are separate straight-line loops so that no register is merged across roles.
+template <bool LEAD>
+__device__ __forceinline__ void k_loop(const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], int pb) {
+    uint4 a[4][2] = {}, w[2][2] = {};                        // [fragment][kk]
+    // Fragment reads are inline-asm ds_read_b128: hipcc would otherwise put `s_waitcnt vmcnt(0)` in front of every
+    // LDS read while a DMA (an LDS write on the VM counter) is in flight and drain the pipeline each phase.  The
+    // counted waits + barriers below are what orders a read after the DMA that produced its data.  Offsets are
+    // literal immediates (the "n" constraint needs constants, hence the macro expansion).
+#if ABL_NOREAD
+#define DSR(dst, addr, off) asm volatile("; no read %0 %1" : "=v"(dst) : "v"(addr))
+#else
 #define DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#endif
 #define RD_A(half)                                                  \
     DSR(a[0][0], ba0, ((half) * 64 + 0) * ROWB);  DSR(a[0][1], ba1, ((half) * 64 + 0) * ROWB);  \
     DSR(a[1][0], ba0, ((half) * 64 + 16) * ROWB); DSR(a[1][1], ba1, ((half) * 64 + 16) * ROWB); \
@@ -98,82 +113,78 @@ struct LoopCtx {
                 Mma<bf16_t>::run(acc[(mhalf) * 4 + f][(nhalf) * 2 + h], w[h][kk], a[f][kk]);     \
         __builtin_amdgcn_s_setprio(0);                                                           \
     }
-// the wait is invisible to the scheduler too: pin everything behind it (cdna_hip_programming.md 5.4 rule 18)
+    // the wait is invisible to the scheduler too: pin everything behind it (cdna_hip_programming.md 5.4 rule 18)
 #define LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
+#if ABL_NOBAR
+#define BAR __builtin_amdgcn_sched_barrier(0)
+#else
 #define BAR __builtin_amdgcn_s_barrier()
-#define ISSUE(piece) \
-    if constexpr (HAS_NEXT) issue_piece(piece, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, (kt + 1) * KSTEP, nxt, c.wave);
+#endif
+#ifndef PM_DMA_SPLIT
+#define PM_DMA_SPLIT 0
+#endif
+    // The two DMA instructions of a wave's piece: PM_DMA_SPLIT of them go behind the MFMAs of the wave's compute slot, the
+    // rest behind the fragment reads of its read slot.  ISSUE_A / ISSUE_B = first / second slot of the phase (lead: read
+    // slot then compute slot; lag: compute slot then read slot).
+#define ISSUE_RANGE(piece, lo, hi) \
+    if (has_next && (lo) < (hi) && !ABL_NODMA) issue_piece(piece, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, (kt + 1) * KSTEP, nxt, c.wave, lo, hi);
+#define ISSUE_A(piece) ISSUE_RANGE(piece, 0, (LEAD ? 2 - PM_DMA_SPLIT : PM_DMA_SPLIT))
+#define ISSUE_B(piece) ISSUE_RANGE(piece, (LEAD ? 2 - PM_DMA_SPLIT : PM_DMA_SPLIT), 2)
 #define WAIT(last_n)                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    if constexpr (HAS_NEXT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                     \
-    else if constexpr ((last_n) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");           \
-    else if constexpr ((last_n) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           \
-    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                               \
+    else if ((last_n) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                     \
+    else if ((last_n) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-// One K-tile for one wave.  LEAD = true: waves with wm = 0 ({reads | MFMAs}); LEAD = false: waves with wm = 1, one slot
-// behind ({MFMAs of the previous phase | reads}).  Both roles execute the SAME sequence of barriers, DMA issues and vmcnt
-// waits.  HAS_NEXT (a next K-tile exists: DMA issue, counted waits) and FIRST (the lag wave has no previous phase yet) are
-// compile-time: with run-time flags hipcc merged the `if (has_next)` blocks of a phase and hoisted the phase-end vmcnt wait
-// into the read slot, in front of the barrier and the MFMAs it was placed behind.
-// A read slot is {fragment reads, DMA issue} with NO wait: the reads' LDS latency runs under the DMA issue and the
-// barrier, and the lgkmcnt(0) heads the wave's NEXT slot, right before the MFMAs that consume them.  The DMA goes behind the
-// reads of the wave's read slot, i.e. while the other wave of the SIMD runs MFMAs (behind the wave's own MFMAs it measured
-// 2-5 % slower).
-template <bool LEAD, bool HAS_NEXT, bool FIRST>
-__device__ __forceinline__ void k_tile(const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], uint4 (&a)[4][2], uint4 (&w)[2][2],
-                                       int kt, int pb) {
-    const unsigned boff = (unsigned)((kt + pb) & 1) * BUF_BYTES;   // LDS byte addresses of this K-tile's fragments (pb: buffer of K-tile 0)
-    const unsigned ba0 = c.lds_base + boff + c.fa0, ba1 = c.lds_base + boff + c.fa1;
-    const unsigned bw0 = c.lds_base + boff + c.fw0, bw1 = c.lds_base + boff + c.fw1;
-    unsigned char* nxt = lds + ((kt + 1 + pb) & 1) * BUF_BYTES;
-    // ---------------- phase 1: A rows [0,64) x W rows [0,32)
-    if constexpr (LEAD) { RD_A(0) RD_W(0) ISSUE(PA0) } else if constexpr (!FIRST) { LGKM0; MMA(1, 0) }
-    BAR;
-    if constexpr (LEAD) { LGKM0; MMA(0, 0) } else { RD_A(0) RD_W(0) ISSUE(PA0) }
-    WAIT(2)
-    BAR;
-    // ---------------- phase 2: A rows [0,64) x W rows [32,64)
-    if constexpr (LEAD) { RD_W(1) ISSUE(PW0) } else { LGKM0; MMA(0, 0) }
-    BAR;
-    if constexpr (LEAD) { LGKM0; MMA(0, 1) } else { RD_W(1) ISSUE(PW0) }
-    WAIT(0)
-    BAR;
-    // ---------------- phase 3: A rows [64,128) x W rows [32,64)
-    if constexpr (LEAD) { RD_A(1) ISSUE(PW1) } else { LGKM0; MMA(0, 1) }
-    BAR;
-    if constexpr (LEAD) { LGKM0; MMA(1, 1) } else { RD_A(1) ISSUE(PW1) }
-    WAIT(-1)
-    BAR;
-    // ---------------- phase 4: A rows [64,128) x W rows [0,32) (re-read: cheaper than 16 more live registers)
-    if constexpr (LEAD) { RD_W(0) ISSUE(PA1) } else { LGKM0; MMA(1, 1) }
-    BAR;
-    if constexpr (LEAD) { LGKM0; MMA(1, 0) } else { RD_W(0) ISSUE(PA1) }
-    WAIT(-1)
-    BAR;
-}
-
-// The K loop for one wave: straight-line K-tiles, the first and the last peeled.
-template <bool LEAD>
-__device__ __forceinline__ void k_loop(const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], int pb) {
-    uint4 a[4][2], w[2][2];                        // [fragment][kk]
-    if (c.nk == 1) {
-        k_tile<LEAD, false, true>(c, lds, acc, a, w, 0, pb);
-    } else {
-        k_tile<LEAD, true, true>(c, lds, acc, a, w, 0, pb);
-        for (int kt = 1; kt + 1 < c.nk; ++kt) k_tile<LEAD, true, false>(c, lds, acc, a, w, kt, pb);
-        k_tile<LEAD, false, false>(c, lds, acc, a, w, c.nk - 1, pb);
+    for (int kt = 0; kt < c.nk; ++kt) {
+        const bool has_next = kt + 1 < c.nk;
+        const unsigned boff = (unsigned)((kt + pb) & 1) * BUF_BYTES;   // LDS byte addresses of this K-tile's fragments (pb: buffer of K-tile 0)
+        const unsigned ba0 = c.lds_base + boff + c.fa0, ba1 = c.lds_base + boff + c.fa1;
+        const unsigned bw0 = c.lds_base + boff + c.fw0, bw1 = c.lds_base + boff + c.fw1;
+        unsigned char* nxt = lds + ((kt + 1 + pb) & 1) * BUF_BYTES;
+        // Every wave issues its DMA piece in ITS fragment-read slot (lead: first slot, lag: second slot), i.e. while the
+        // other wave of the SIMD runs MFMAs: a DMA instruction holds the issuing wave for ~60 cycles, which in front of
+        // the lag wave's MFMAs (with the lead wave busy reading) would idle the matrix pipe.  The piece still precedes
+        // the phase's WAIT, so the vmcnt arithmetic is the same for both roles.
+        // ---------------- phase 1: A rows [0,64) x W rows [0,32)
+        // A reader slot is {fragment reads, DMA issue} with NO wait: the reads' LDS latency runs under the DMA issue and
+        // the barrier, and the lgkmcnt(0) sits at the head of the wave's NEXT slot, right before the MFMAs that consume them.
+        // Within a phase the order of a wave's two DMA instructions and the phase's WAIT is the same for both roles.
+        if constexpr (LEAD) { RD_A(0) RD_W(0) ISSUE_A(PA0) } else { if (kt > 0) { LGKM0; MMA(1, 0) } ISSUE_A(PA0) }
+        BAR;
+        if constexpr (LEAD) { LGKM0; MMA(0, 0) ISSUE_B(PA0) } else { RD_A(0) RD_W(0) ISSUE_B(PA0) }
+        WAIT(2)
+        BAR;
+        // ---------------- phase 2: A rows [0,64) x W rows [32,64)
+        if constexpr (LEAD) { RD_W(1) ISSUE_A(PW0) } else { LGKM0; MMA(0, 0) ISSUE_A(PW0) }
+        BAR;
+        if constexpr (LEAD) { LGKM0; MMA(0, 1) ISSUE_B(PW0) } else { RD_W(1) ISSUE_B(PW0) }
+        WAIT(0)
+        BAR;
+        // ---------------- phase 3: A rows [64,128) x W rows [32,64)
+        if constexpr (LEAD) { RD_A(1) ISSUE_A(PW1) } else { LGKM0; MMA(0, 1) ISSUE_A(PW1) }
+        BAR;
+        if constexpr (LEAD) { LGKM0; MMA(1, 1) ISSUE_B(PW1) } else { RD_A(1) ISSUE_B(PW1) }
+        WAIT(-1)
+        BAR;
+        // ---------------- phase 4: A rows [64,128) x W rows [0,32) (re-read: cheaper than 16 more live registers)
+        if constexpr (LEAD) { RD_W(0) ISSUE_A(PA1) } else { LGKM0; MMA(1, 1) ISSUE_A(PA1) }
+        BAR;
+        if constexpr (LEAD) { LGKM0; MMA(1, 0) ISSUE_B(PA1) } else { RD_W(0) ISSUE_B(PA1) }
+        WAIT(-1)
+        BAR;
     }
     if constexpr (!LEAD) { LGKM0; MMA(1, 0) }
-}
 #undef DSR
 #undef RD_A
 #undef RD_W
 #undef MMA
 #undef LGKM0
 #undef BAR
-#undef ISSUE
+#undef ISSUE_RANGE
+#undef ISSUE_A
+#undef ISSUE_B
 #undef WAIT
-
+}
 
 // FOLD: LayerNorm folded into this GEMM (gemm_common.h): A is the raw bf16 residual row, the epilogue normalises.
 template <int EPI, typename OutT, bool FOLD = false>
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     const int ntiles = (p.M / BM) * (p.N / BN);
     const int tiles_m = p.M / BM, tiles_n = p.N / BN;
     LoopCtx c;
-    c.lda_b = (unsigned)p.lda * 2u; c.ldw_b = (unsigned)p.ldw * 2u;
+    c.lda_b = (size_t)p.lda * 2; c.ldw_b = (size_t)p.ldw * 2;
     const unsigned lswz = (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);       // chunk rows start at multiples of 8
     c.laneoffA = (unsigned)(lane >> 3) * (unsigned)c.lda_b + lswz;
     c.laneoffW = (unsigned)(lane >> 3) * (unsigned)c.ldw_b + lswz;
@@ -214,16 +225,16 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     };
     int tile = blockIdx.x, m0, n0;
     origin(tile, m0, n0);
-    c.Ar = tile_rsrc(reinterpret_cast<const unsigned char*>(p.A) + (size_t)m0 * c.lda_b);
-    c.Wr = tile_rsrc(reinterpret_cast<const unsigned char*>(p.W) + (size_t)n0 * c.ldw_b);
+    c.Ab = reinterpret_cast<const unsigned char*>(p.A) + (size_t)m0 * c.lda_b;
+    c.Wb = reinterpret_cast<const unsigned char*>(p.W) + (size_t)n0 * c.ldw_b;
 
     // prologue of the FIRST tile: its whole first K-tile, in need-order; PA0 + PW0 must have landed before phase 1
     LnLoads lnl;
     if constexpr (FOLD) ln_stats_issue(p, m0 + wm * 128, n0 + wn * 64, lane, lnl);      // before the DMA: these return first
-    issue_piece(PA0, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
-    issue_piece(PW0, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
-    issue_piece(PW1, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
-    issue_piece(PA1, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PA0, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PW0, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PW1, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PA1, c.Ab, c.Wb, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     float fa[FOLD ? 8 : 1], fb[FOLD ? 8 : 1];
     float* fscr = reinterpret_cast<float*>(lds + 2 * BUF_BYTES + (FOLD ? wave * 2048 : 0));
     if constexpr (FOLD) ln_row_coeffs<8>(p, lane, fscr, lnl, fa, fb);        // 4 pieces x 2 DMA instructions stay in flight
@@ -246,15 +257,15 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
         const bool has_next = next < ntiles;
         int m1 = 0, n1 = 0;
         if (has_next) origin(next, m1, n1);
-        const rsrc_t Ar1 = tile_rsrc(reinterpret_cast<const unsigned char*>(p.A) + (size_t)m1 * c.lda_b);
-        const rsrc_t Wr1 = tile_rsrc(reinterpret_cast<const unsigned char*>(p.W) + (size_t)n1 * c.ldw_b);
+        const unsigned char* Ab1 = reinterpret_cast<const unsigned char*>(p.A) + (size_t)m1 * c.lda_b;
+        const unsigned char* Wb1 = reinterpret_cast<const unsigned char*>(p.W) + (size_t)n1 * c.ldw_b;
         auto prefetch = [&]() {
             if (has_next) {
                 unsigned char* b1 = lds + BUF_BYTES;
-                issue_piece(PA0, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
-                issue_piece(PW0, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
-                issue_piece(PW1, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
-                issue_piece(PA1, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+                issue_piece(PA0, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+                issue_piece(PW0, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+                issue_piece(PW1, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
+                issue_piece(PA1, Ab1, Wb1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
             }
         };
         if constexpr (FOLD) ln_apply<8>(fscr, acc, lane, fa, fb);
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // every wave is done staging through buffer 0; the K-tile is visible
         tile = next; m0 = m1; n0 = n1;
-        c.Ar = Ar1; c.Wr = Wr1;
+        c.Ab = Ab1; c.Wb = Wb1;
         pb = 1;
     }
 }
