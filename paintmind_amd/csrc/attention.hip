@@ -99,6 +99,24 @@ __device__ __forceinline__ void stage_tiles(unsigned char* stage, const unsigned
     }
 }
 
+// bf16 form of stage_tiles on `buffer_load_dwordx4 ... lds`: descriptors based at the (batch, head)'s K / V^T, ONE per-lane
+// vector offset each (row-in-chunk and swizzled slot do not depend on the chunk: chunks start at multiples of 8 rows), the
+// chunk / tile position in the scalar offset -- no VALU address arithmetic per instruction.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ void stage_tiles_bf16(unsigned char* stage, rsrc_t Kr, rsrc_t Vr, unsigned kvoff, unsigned vvoff,
+                                                 unsigned v_row_bytes, int t, int wave) {
+    constexpr int PER_WAVE = 2;                          // 8 chunks of 8 rows per tile, 4 waves
+    const unsigned kv0 = (unsigned)t * KT;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const unsigned chunk = (unsigned)wave * PER_WAVE + i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Kr, (__attribute__((address_space(3))) void*)(stage + chunk * 1024), 16, kvoff,
+                                                 (kv0 + chunk * 8) * 128u, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Vr, (__attribute__((address_space(3))) void*)(stage + KT * 128 + chunk * 1024), 16, vvoff,
+                                                 chunk * 8 * v_row_bytes + kv0 * 2u, 0, 0);
+    }
+}
+
 // ragged last tile: zero the V^T columns of keys >= Nkv (K needs nothing: those scores are masked to -inf)
 template <typename T>
 __device__ __forceinline__ void zero_ragged_v(unsigned char* Vl, int kv0, int Nkv, int tid) {
@@ -146,6 +164,31 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
     const unsigned char* Kbh = reinterpret_cast<const unsigned char*>(Kp + (size_t)bh * Nkv_pad * DH);
     const unsigned char* Vbh = reinterpret_cast<const unsigned char*>(Vt + (size_t)bh * DH * Nkv_pad);
     const size_t v_row_bytes = (size_t)Nkv_pad * sizeof(T);
+    // bf16: DMA descriptors / lane offsets, and the per-lane parts of the fragment addresses.  Fragment reads are inline-asm
+    // ds_read_b128 with immediate offsets: with C++ LDS reads hipcc puts `s_waitcnt vmcnt(0)` in front of the first read
+    // after the DMA issue, i.e. it waits for the NEXT tile's DMA right after issuing it (measured: 200 -> 171 us with the
+    // DMA removed).  The explicit vmcnt(0) + barrier in enter_tile() is what orders reads after the DMA that fed them.
+    //   K row of S^T tile kf = 2 pc + kk, row i = l15:  32 pc + 8 (l15 >> 2) + 4 kk + (l15 & 3);  slot (4 c + g) ^ (row & 7)
+    //     = stage + [8 (l15 >> 2) + (l15 & 3)] * 128 + (g ^ (l15 & 3)) * 16  +  pc * 4096 + kk * 512 + (c ^ kk) * 64
+    //   V^T row 16 df + l15, slot (4 pc + g) ^ (l15 & 7)
+    //     = stage + 8192 + l15 * 128 + ((4 pc + g) ^ (l15 & 7)) * 16  +  df * 2048
+    [[maybe_unused]] rsrc_t Kr, Vr;
+    [[maybe_unused]] unsigned kvoff = 0, vvoff = 0, kfrag_lane = 0, vfrag_lane0 = 0, vfrag_lane1 = 0;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    if constexpr (sizeof(T) == 2) {
+        Kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Kbh), 0, 0x7fffffff, 0x00020000);
+        Vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Vbh), 0, 0x7fffffff, 0x00020000);
+        const unsigned lslot = (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+        kvoff = (unsigned)(lane >> 3) * 128u + lslot;
+        vvoff = (unsigned)(lane >> 3) * (unsigned)v_row_bytes + lslot;
+        kfrag_lane = lds_base + (unsigned)(8 * (l15 >> 2) + (l15 & 3)) * 128u + (unsigned)((g ^ (l15 & 3)) << 4);
+        vfrag_lane0 = lds_base + 8192u + (unsigned)l15 * 128u + (unsigned)(((0 + g) ^ (l15 & 7)) << 4);
+        vfrag_lane1 = lds_base + 8192u + (unsigned)l15 * 128u + (unsigned)(((4 + g) ^ (l15 & 7)) << 4);
+    }
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+#define DSRX(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    // the wait names the fragments as in/out operands, so every MFMA that consumes one is ordered behind it
+#define LGKM_N(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f))
 
     // Q fragments stay in registers for the whole kernel (column operand of S^T)
     uint4 qreg[QF][C::NCH];
@@ -177,10 +220,42 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     constexpr int LOADS_PER_TILE = 2 * ((KT / (1024 / C::ROWB)) / 4);   // DMA instructions per wave per tile (K + V^T)
 
+    // bf16: issue the 4 K-fragment reads of half-tile hh ([kk][c]); they are waited for, one by one, in front of the MFMAs that
+    // consume them (qk_half), so whatever the caller puts in between runs under their LDS latency.  Counted lgkmcnt is exact
+    // here because LDS operations return in order and the loop has no scalar loads (checked in the ISA: all s_load are in
+    // the kernel prologue).
+    auto k_issue = [&](v4u_t (&kf)[2][2], int hh) {
+        if constexpr (sizeof(T) == 2) {
+            const unsigned ka = kfrag_lane + (unsigned)((hh >> 1) % 3) * STAGE_BYTES + (unsigned)(hh & 1) * 4096u;
+            DSRX(kf[0][0], ka, 0 * 512 + 0 * 64); DSRX(kf[0][1], ka, 0 * 512 + 1 * 64);
+            DSRX(kf[1][0], ka, 1 * 512 + 1 * 64); DSRX(kf[1][1], ka, 1 * 512 + 0 * 64);
+        }
+    };
+
     // S^T of one half-tile: 2 key tiles x QF query tiles
-    auto qk_half = [&](f32x4_t (&sd)[2][QF], int hh) {
+    auto qk_half = [&](f32x4_t (&sd)[2][QF], int hh, v4u_t (&kf)[2][2]) {
         const unsigned char* Kl = lds + ((hh >> 1) % 3) * STAGE_BYTES;
         const int pc = hh & 1;
+        if constexpr (sizeof(T) == 2) {
+            (void)Kl; (void)pc;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int qf = 0; qf < QF; ++qf) sd[kk][qf] = negm[qf];
+            LGKM_N(3, kf[0][0]);
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) Mma<T>::run(sd[0][qf], __builtin_bit_cast(uint4, kf[0][0]), qreg[qf][0]);
+            LGKM_N(2, kf[0][1]);
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) Mma<T>::run(sd[0][qf], __builtin_bit_cast(uint4, kf[0][1]), qreg[qf][1]);
+            LGKM_N(1, kf[1][0]);
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) Mma<T>::run(sd[1][qf], __builtin_bit_cast(uint4, kf[1][0]), qreg[qf][0]);
+            LGKM_N(0, kf[1][1]);
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) Mma<T>::run(sd[1][qf], __builtin_bit_cast(uint4, kf[1][1]), qreg[qf][1]);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -247,9 +322,9 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
     // (2) ONE basic block: the exponentials / row sums / bf16 packing of half-tile hh (VALU + transcendental) and,
     // when there is a next half-tile, the 16 MFMAs of its S^T -- independent work, interleaved by the scheduler
     // directives below so the matrix pipe runs under the softmax instead of after it.
-    auto exp_and_next_qk = [&](auto has_next_c, f32x4_t (&sc)[2][QF], uint4 (&pfrag)[2][QF], f32x4_t (&sn)[2][QF], int hn) {
+    auto exp_and_next_qk = [&](auto has_next_c, f32x4_t (&sc)[2][QF], uint4 (&pfrag)[2][QF], f32x4_t (&sn)[2][QF], int hn, v4u_t (&kf)[2][2]) {
         constexpr bool has_next = decltype(has_next_c)::value;      // compile-time: the steady-state region has no branch
-        if constexpr (has_next) qk_half(sn, hn);
+        if constexpr (has_next) qk_half(sn, hn, kf);
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
             float psum = 0.f;
@@ -275,7 +350,6 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
             {
                 // 4 K-fragment reads, then 16 x {1 MFMA, 2 transcendental}; the pack / row-sum VALU depend on exps of later groups
                 // and are left to the scheduler (a VALU group inside the pattern makes it infeasible and it is dropped whole)
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -290,12 +364,22 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
         const int t = hh >> 1, pc = hh & 1;
         const unsigned char* Vl = lds + (t % 3) * STAGE_BYTES + TILE_BYTES;
         if constexpr (sizeof(T) == 2) {
+            (void)Vl;
+            const unsigned va = (pc ? vfrag_lane1 : vfrag_lane0) + (unsigned)(t % 3) * STAGE_BYTES;
+            v4u_t vf[4];
+            DSRX(vf[0], va, 0 * 2048); DSRX(vf[1], va, 1 * 2048); DSRX(vf[2], va, 2 * 2048); DSRX(vf[3], va, 3 * 2048);
+            LGKM_N(3, vf[0]);
 #pragma unroll
-            for (int df = 0; df < 4; ++df) {
-                const uint4 vfrag = lds_chunk<T>(Vl, df * 16 + l15, pc * 4 + g);
+            for (int qf = 0; qf < QF; ++qf) Mma<T>::run(o[0][qf], __builtin_bit_cast(uint4, vf[0]), pfrag[0][qf]);
+            LGKM_N(2, vf[1]);
 #pragma unroll
-                for (int qf = 0; qf < QF; ++qf) Mma<T>::run(o[df][qf], vfrag, pfrag[0][qf]);
-            }
+            for (int qf = 0; qf < QF; ++qf) Mma<T>::run(o[1][qf], __builtin_bit_cast(uint4, vf[1]), pfrag[0][qf]);
+            LGKM_N(1, vf[2]);
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) Mma<T>::run(o[2][qf], __builtin_bit_cast(uint4, vf[2]), pfrag[0][qf]);
+            LGKM_N(0, vf[3]);
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) Mma<T>::run(o[3][qf], __builtin_bit_cast(uint4, vf[3]), pfrag[0][qf]);
         } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -314,14 +398,18 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
     auto enter_tile = [&](int tn) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tn + 1 < ntiles) stage_tiles<T>(lds + ((tn + 1) % 3) * STAGE_BYTES, Kbh, Vbh, v_row_bytes, tn + 1, wave_u, lane);
+        if (tn + 1 < ntiles) {
+            if constexpr (sizeof(T) == 2) stage_tiles_bf16(lds + ((tn + 1) % 3) * STAGE_BYTES, Kr, Vr, kvoff, vvoff, (unsigned)v_row_bytes, tn + 1, wave_u);
+            else stage_tiles<T>(lds + ((tn + 1) % 3) * STAGE_BYTES, Kbh, Vbh, v_row_bytes, tn + 1, wave_u, lane);
+        }
         if (tn * KT + KT > Nkv) {
             zero_ragged_v<T>(lds + (tn % 3) * STAGE_BYTES + TILE_BYTES, tn * KT, Nkv, tid);
             __syncthreads();
         }
     };
 
-    stage_tiles<T>(lds, Kbh, Vbh, v_row_bytes, 0, wave_u, lane);
+    if constexpr (sizeof(T) == 2) stage_tiles_bf16(lds, Kr, Vr, kvoff, vvoff, (unsigned)v_row_bytes, 0, wave_u);
+    else stage_tiles<T>(lds, Kbh, Vbh, v_row_bytes, 0, wave_u, lane);
     (void)LOADS_PER_TILE;
     enter_tile(0);
 
@@ -331,26 +419,32 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
     uint4 pfrag[2][QF];
     constexpr std::true_type kNext{};
     constexpr std::false_type kLast{};
-    qk_half(sA, 0);
+    v4u_t kf[2][2];
+    k_issue(kf, 0);
+    qk_half(sA, 0, kf);
     int hs = 0;
     for (; hs + 2 < nhalves; hs += 2) {                                  // steady state: both following halves exist
+        k_issue(kf, hs + 1);                                            // same tile: the row max runs under the reads
         rowmax_rescale(sA, hs);
-        exp_and_next_qk(kNext, sA, pfrag, sB, hs + 1);                  // S^T(hs+1): same tile, second half
+        exp_and_next_qk(kNext, sA, pfrag, sB, hs + 1, kf);              // S^T(hs+1): same tile, second half
         pv_half(pfrag, hs);
-        rowmax_rescale(sB, hs + 1);
         enter_tile((hs + 2) >> 1);                                      // S^T(hs+2) opens the next tile
-        exp_and_next_qk(kNext, sB, pfrag, sA, hs + 2);
+        k_issue(kf, hs + 2);
+        rowmax_rescale(sB, hs + 1);
+        exp_and_next_qk(kNext, sB, pfrag, sA, hs + 2, kf);
         pv_half(pfrag, hs + 1);
     }
-    rowmax_rescale(sA, hs);                                             // tail: one or two halves left
-    if (hs + 1 < nhalves) {
-        exp_and_next_qk(kNext, sA, pfrag, sB, hs + 1);
+    if (hs + 1 < nhalves) {                                             // tail: one or two halves left
+        k_issue(kf, hs + 1);
+        rowmax_rescale(sA, hs);
+        exp_and_next_qk(kNext, sA, pfrag, sB, hs + 1, kf);
         pv_half(pfrag, hs);
         rowmax_rescale(sB, hs + 1);
-        exp_and_next_qk(kLast, sB, pfrag, sA, 0);
+        exp_and_next_qk(kLast, sB, pfrag, sA, 0, kf);
         pv_half(pfrag, hs + 1);
     } else {
-        exp_and_next_qk(kLast, sA, pfrag, sB, 0);
+        rowmax_rescale(sA, hs);
+        exp_and_next_qk(kLast, sA, pfrag, sB, 0, kf);
         pv_half(pfrag, hs);
     }
 
@@ -372,6 +466,9 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
         }
     }
 }
+
+#undef DSRX
+#undef LGKM_N
 
 }  // namespace
 
