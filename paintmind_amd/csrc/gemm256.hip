@@ -43,8 +43,8 @@ __device__ __forceinline__ int piece_row(int piece, int c) {
     return grp * 64 + within + (piece == PW1 ? 32 : 0);
 }
 
-// A piece = 16 chunks of 8 rows; wave w DMAs chunks 2w, 2w+1 with `buffer_load_dwordx4 ... lds`: the operand's tile origin
-// is the base of a buffer descriptor (SGPRs), the chunk row and the k offset form the scalar offset, and ONE per-lane byte
+// A piece = 16 chunks of 8 rows; wave w DMAs chunks 2w, 2w+1 with `buffer_load_dwordx4 ... lds`: one buffer descriptor per
+// operand for the whole kernel (SGPRs), the tile origin + chunk row + k offset form the scalar offset, and ONE per-lane byte
 // offset per operand (row-in-chunk * ld + swizzled 16-B slot) is the vector offset -- a DMA instruction costs its wave
 // two SALU operations and no VALU (the flat global_load_lds form needed a 64-bit VALU add per instruction, issued by the
 // read-slot wave while its SIMD partner holds priority for MFMAs).
@@ -52,23 +52,26 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t tile_rsrc(const void* origin) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(origin), 0, 0x7fffffff, 0x00020000);   // raw buffer, no bounds in play
 }
-__device__ __forceinline__ void issue_piece(int piece, rsrc_t Ar, rsrc_t Wr, unsigned lda_b, unsigned ldw_b, unsigned laneoffA,
-                                            unsigned laneoffW, int k0, unsigned char* buf, int wave, int i0 = 0, int i1 = 2) {
+__device__ __forceinline__ void issue_piece(int piece, rsrc_t Ar, rsrc_t Wr, unsigned aorg, unsigned worg, unsigned lda_b, unsigned ldw_b,
+                                            unsigned laneoffA, unsigned laneoffW, int k0, unsigned char* buf, int wave, int i0 = 0, int i1 = 2) {
     const bool isA = (piece == PA0 || piece == PA1);
+    const unsigned org = isA ? aorg : worg;
     const unsigned ld_b = isA ? lda_b : ldw_b;
     const unsigned laneoff = isA ? laneoffA : laneoffW;
     unsigned char* tile = buf + (isA ? 0 : OPER_BYTES);
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
         const int row0 = piece_row(piece, wave * 2 + i);           // wave-uniform
-        const unsigned soff = (unsigned)row0 * ld_b + (unsigned)k0 * 2u;
+        const unsigned soff = org + (unsigned)row0 * ld_b + (unsigned)k0 * 2u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? Ar : Wr, (__attribute__((address_space(3))) void*)(tile + row0 * ROWB), 16, laneoff,
                                                  soff, 0, 0);
     }
 }
 
 struct LoopCtx {
-    rsrc_t Ar, Wr;                                      // buffer descriptors based at the tile origin rows of A / W
+    rsrc_t Ar, Wr;                                      // buffer descriptors of A / W
+    unsigned aorg, worg;                                // byte offsets of the tile's origin rows in A / W
+    unsigned aorg1, worg1;                              // the same for the workgroup's NEXT tile (streamed in by the last K-tile)
     unsigned lda_b, ldw_b;
     unsigned laneoffA, laneoffW;                        // per-lane DMA source offsets
     unsigned fa0, fa1, fw0, fw1;                        // per-lane fragment read offsets (kk = 0, 1)
@@ -101,68 +104,94 @@ struct LoopCtx {
 // the wait is invisible to the scheduler too: pin everything behind it (cdna_hip_programming.md 5.4 rule 18)
 #define LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
 #define BAR __builtin_amdgcn_s_barrier()
-#define ISSUE(piece) \
-    if constexpr (HAS_NEXT) issue_piece(piece, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, (kt + 1) * KSTEP, nxt, c.wave);
-#define WAIT(last_n)                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    if constexpr (HAS_NEXT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                     \
-    else if constexpr ((last_n) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");           \
-    else if constexpr ((last_n) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           \
-    __builtin_amdgcn_sched_barrier(0);
+#define VMW(n) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 
-// One K-tile for one wave.  LEAD = true: waves with wm = 0 ({reads | MFMAs}); LEAD = false: waves with wm = 1, one slot
-// behind ({MFMAs of the previous phase | reads}).  Both roles execute the SAME sequence of barriers, DMA issues and vmcnt
-// waits.  HAS_NEXT (a next K-tile exists: DMA issue, counted waits) and FIRST (the lag wave has no previous phase yet) are
-// compile-time: with run-time flags hipcc merged the `if (has_next)` blocks of a phase and hoisted the phase-end vmcnt wait
-// into the read slot, in front of the barrier and the MFMAs it was placed behind.
+// K-tile kinds.  They differ in what the tile's read slots DMA and in the phase-end vmcnt waits; the fragment reads, MFMAs
+// and barriers are identical.  All of it is compile-time: with run-time flags hipcc merged the `if (has_next)` blocks of a
+// phase and hoisted the phase-end vmcnt wait into the read slot, in front of the barrier and the MFMAs it was placed behind
+// (and every extra variant on a run-time branch costs accumulator spills at the joins, hence exactly three kinds).
+//   KT_STEADY  next K-tile of the same output tile, one piece per phase (PA0, PW0, PW1, PA1); every wait is vmcnt(4): the two
+//              youngest pieces may still be flying
+//   KT_FIRST   first K-tile of an output tile.  All four of its pieces have landed (prologue, or KT_LAST of the previous tile),
+//              and the only younger VMEM operations are the previous epilogue's STORES: phases 1-3 do not wait at all, so the
+//              stores drain under three phases of MFMAs; phase 4 needs the first two pieces of the next K-tile and therefore
+//              (vmcnt retires in issue order: AMDGPU memory model, tools/hwtests/vmcnt_order.hip) the stores.  The lag wave
+//              has no previous phase to multiply.
+//   KT_LAST    the tile's last K-tile.  The first K-tile of the workgroup's NEXT output tile is DMA'd into the other buffer --
+//              dead since the previous K-tile -- two pieces in each of phases 1 and 2, nothing afterwards, so the closing
+//              vmcnt(0) waits for loads that are >= 2 phases old and the epilogue starts with no VMEM load of this wave in
+//              flight.  Waits: phase 1 needs PW1 (outstanding: PA1 + 4 new = 6), phase 2 needs PA1 (8 new).  A workgroup
+//              without a next tile re-reads its own tile's first K-tile (64 KiB from L2, once per workgroup) rather than
+//              carrying a fourth variant.
+enum { KT_STEADY = 0, KT_FIRST = 1, KT_LAST = 2 };
+
 // A read slot is {fragment reads, DMA issue} with NO wait: the reads' LDS latency runs under the DMA issue and the
 // barrier, and the lgkmcnt(0) heads the wave's NEXT slot, right before the MFMAs that consume them.  The DMA goes behind the
 // reads of the wave's read slot, i.e. while the other wave of the SIMD runs MFMAs (behind the wave's own MFMAs it measured
-// 2-5 % slower).
-template <bool LEAD, bool HAS_NEXT, bool FIRST>
+// 2-5 % slower).  LEAD = true: waves with wm = 0 ({reads | MFMAs}); LEAD = false: waves with wm = 1, one slot behind
+// ({MFMAs of the previous phase | reads}).  Both roles execute the SAME sequence of barriers, DMA issues and vmcnt waits.
+template <bool LEAD, int KIND>
 __device__ __forceinline__ void k_tile(const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], uint4 (&a)[4][2], uint4 (&w)[2][2],
                                        int kt, int pb) {
+    constexpr bool FIRST = KIND == KT_FIRST;
+    constexpr bool ONE_PER_PHASE = KIND != KT_LAST;
     const unsigned boff = (unsigned)((kt + pb) & 1) * BUF_BYTES;   // LDS byte addresses of this K-tile's fragments (pb: buffer of K-tile 0)
     const unsigned ba0 = c.lds_base + boff + c.fa0, ba1 = c.lds_base + boff + c.fa1;
     const unsigned bw0 = c.lds_base + boff + c.fw0, bw1 = c.lds_base + boff + c.fw1;
     unsigned char* nxt = lds + ((kt + 1 + pb) & 1) * BUF_BYTES;
+#define ISSUE(piece) issue_piece(piece, c.Ar, c.Wr, c.aorg, c.worg, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, (kt + 1) * KSTEP, nxt, c.wave);
+#define ISSUE_NEXT_TILE(piece) issue_piece(piece, c.Ar, c.Wr, c.aorg1, c.worg1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, nxt, c.wave);
+#define DMA(phase)                                                                                                   \
+    if constexpr (ONE_PER_PHASE) {                                                                                   \
+        if constexpr (phase == 1) { ISSUE(PA0) } else if constexpr (phase == 2) { ISSUE(PW0) }                       \
+        else if constexpr (phase == 3) { ISSUE(PW1) } else { ISSUE(PA1) }                                            \
+    } else {                                                                                                         \
+        if constexpr (phase == 1) { ISSUE_NEXT_TILE(PA0) ISSUE_NEXT_TILE(PW0) }                                      \
+        else if constexpr (phase == 2) { ISSUE_NEXT_TILE(PW1) ISSUE_NEXT_TILE(PA1) }                                 \
+    }
+#define WAIT(phase)                                                                                                  \
+    if constexpr (KIND == KT_STEADY) VMW(4)                                                                          \
+    else if constexpr (KIND == KT_FIRST) { if constexpr (phase == 4) VMW(4) }                                        \
+    else {                                                                                                           \
+        if constexpr (phase == 1) VMW(6) else if constexpr (phase == 2) VMW(8) else if constexpr (phase == 4) VMW(0) \
+    }
     // ---------------- phase 1: A rows [0,64) x W rows [0,32)
-    if constexpr (LEAD) { RD_A(0) RD_W(0) ISSUE(PA0) } else if constexpr (!FIRST) { LGKM0; MMA(1, 0) }
+    if constexpr (LEAD) { RD_A(0) RD_W(0) DMA(1) } else if constexpr (!FIRST) { LGKM0; MMA(1, 0) }
     BAR;
-    if constexpr (LEAD) { LGKM0; MMA(0, 0) } else { RD_A(0) RD_W(0) ISSUE(PA0) }
-    WAIT(2)
+    if constexpr (LEAD) { LGKM0; MMA(0, 0) } else { RD_A(0) RD_W(0) DMA(1) }
+    WAIT(1)
     BAR;
     // ---------------- phase 2: A rows [0,64) x W rows [32,64)
-    if constexpr (LEAD) { RD_W(1) ISSUE(PW0) } else { LGKM0; MMA(0, 0) }
+    if constexpr (LEAD) { RD_W(1) DMA(2) } else { LGKM0; MMA(0, 0) }
     BAR;
-    if constexpr (LEAD) { LGKM0; MMA(0, 1) } else { RD_W(1) ISSUE(PW0) }
-    WAIT(0)
+    if constexpr (LEAD) { LGKM0; MMA(0, 1) } else { RD_W(1) DMA(2) }
+    WAIT(2)
     BAR;
     // ---------------- phase 3: A rows [64,128) x W rows [32,64)
-    if constexpr (LEAD) { RD_A(1) ISSUE(PW1) } else { LGKM0; MMA(0, 1) }
+    if constexpr (LEAD) { RD_A(1) DMA(3) } else { LGKM0; MMA(0, 1) }
     BAR;
-    if constexpr (LEAD) { LGKM0; MMA(1, 1) } else { RD_A(1) ISSUE(PW1) }
-    WAIT(-1)
+    if constexpr (LEAD) { LGKM0; MMA(1, 1) } else { RD_A(1) DMA(3) }
+    WAIT(3)
     BAR;
     // ---------------- phase 4: A rows [64,128) x W rows [0,32) (re-read: cheaper than 16 more live registers)
-    if constexpr (LEAD) { RD_W(0) ISSUE(PA1) } else { LGKM0; MMA(1, 1) }
+    if constexpr (LEAD) { RD_W(0) DMA(4) } else { LGKM0; MMA(1, 1) }
     BAR;
-    if constexpr (LEAD) { LGKM0; MMA(1, 0) } else { RD_W(0) ISSUE(PA1) }
-    WAIT(-1)
+    if constexpr (LEAD) { LGKM0; MMA(1, 0) } else { RD_W(0) DMA(4) }
+    WAIT(4)
     BAR;
+#undef ISSUE
+#undef ISSUE_NEXT_TILE
+#undef DMA
+#undef WAIT
 }
 
-// The K loop for one wave: straight-line K-tiles, the first and the last peeled.
+// The K loop of one output tile for one wave: straight-line K-tiles, the first and the last peeled (nk >= 2).
 template <bool LEAD>
 __device__ __forceinline__ void k_loop(const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], int pb) {
     uint4 a[4][2], w[2][2];                        // [fragment][kk]
-    if (c.nk == 1) {
-        k_tile<LEAD, false, true>(c, lds, acc, a, w, 0, pb);
-    } else {
-        k_tile<LEAD, true, true>(c, lds, acc, a, w, 0, pb);
-        for (int kt = 1; kt + 1 < c.nk; ++kt) k_tile<LEAD, true, false>(c, lds, acc, a, w, kt, pb);
-        k_tile<LEAD, false, false>(c, lds, acc, a, w, c.nk - 1, pb);
-    }
+    k_tile<LEAD, KT_FIRST>(c, lds, acc, a, w, 0, pb);
+    for (int kt = 1; kt + 1 < c.nk; ++kt) k_tile<LEAD, KT_STEADY>(c, lds, acc, a, w, kt, pb);
+    k_tile<LEAD, KT_LAST>(c, lds, acc, a, w, c.nk - 1, pb);
     if constexpr (!LEAD) { LGKM0; MMA(1, 0) }
 }
 #undef DSR
@@ -171,8 +200,7 @@ __device__ __forceinline__ void k_loop(const LoopCtx& c, unsigned char* lds, f32
 #undef MMA
 #undef LGKM0
 #undef BAR
-#undef ISSUE
-#undef WAIT
+#undef VMW
 
 
 // FOLD: LayerNorm folded into this GEMM (gemm_common.h): A is the raw bf16 residual row, the epilogue normalises.
@@ -186,10 +214,12 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
 
-    // PERSISTENT: the grid holds at most one workgroup per CU; workgroup w walks tiles w, w + grid, ... of the same XCD /
-    // L2-aware order.  While a tile's epilogue runs, the first K-tile of the NEXT tile is already in flight (issued from
-    // the epilogue's hook into the LDS buffer the epilogue does not stage through), so only the first tile of a
-    // workgroup pays the DMA latency of its prologue, and a tile's stores drain under the next tile's K loop.
+    // PERSISTENT and STREAMED: the grid holds at most one workgroup per CU; workgroup w walks tiles w, w + grid, ... of the
+    // same XCD / L2-aware order, and the K-tiles of consecutive output tiles form ONE stream through the two LDS buffers: the
+    // last K-tile of a tile DMAs the first K-tile of the next one (k_tile kinds above).  The epilogue stages through the
+    // buffer of the tile's last K-tile and starts with no load of its wave in flight; its stores are waited for three phases
+    // into the next tile's K loop (they used to be waited for at the tile boundary: removing the stores alone took the
+    // head-split QKV GEMM from 128 to 104 us, i.e. the store drain was fully exposed).
     const int ntiles = (p.M / BM) * (p.N / BN);
     const int tiles_m = p.M / BM, tiles_n = p.N / BN;
     LoopCtx c;
@@ -214,20 +244,21 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     };
     int tile = blockIdx.x, m0, n0;
     origin(tile, m0, n0);
-    c.Ar = tile_rsrc(reinterpret_cast<const unsigned char*>(p.A) + (size_t)m0 * c.lda_b);
-    c.Wr = tile_rsrc(reinterpret_cast<const unsigned char*>(p.W) + (size_t)n0 * c.ldw_b);
+    c.Ar = tile_rsrc(p.A);
+    c.Wr = tile_rsrc(p.W);
+    c.aorg = (unsigned)m0 * c.lda_b; c.worg = (unsigned)n0 * c.ldw_b;
 
-    // prologue of the FIRST tile: its whole first K-tile, in need-order; PA0 + PW0 must have landed before phase 1
+    // prologue of the FIRST tile: its whole first K-tile
     LnLoads lnl;
     if constexpr (FOLD) ln_stats_issue(p, m0 + wm * 128, n0 + wn * 64, lane, lnl);      // before the DMA: these return first
-    issue_piece(PA0, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
-    issue_piece(PW0, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
-    issue_piece(PW1, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
-    issue_piece(PA1, c.Ar, c.Wr, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PA0, c.Ar, c.Wr, c.aorg, c.worg, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PW0, c.Ar, c.Wr, c.aorg, c.worg, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PW1, c.Ar, c.Wr, c.aorg, c.worg, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
+    issue_piece(PA1, c.Ar, c.Wr, c.aorg, c.worg, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     float fa[FOLD ? 8 : 1], fb[FOLD ? 8 : 1];
     float* fscr = reinterpret_cast<float*>(lds + 2 * BUF_BYTES + (FOLD ? wave * 2048 : 0));
     if constexpr (FOLD) ln_row_coeffs<8>(p, lane, fscr, lnl, fa, fb);        // 4 pieces x 2 DMA instructions stay in flight
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the whole first K-tile (KT_FIRST takes no waits for it)
     __builtin_amdgcn_s_barrier();
 
     int pb = 0;                                    // LDS buffer that holds K-tile 0 of the current tile
@@ -238,46 +269,32 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-        if (wm == 0) k_loop<true>(c, lds, acc, pb); else k_loop<false>(c, lds, acc, pb);
-
-        // every fragment read finished before the last barrier: both LDS buffers are free.  The epilogue stages through
-        // buffer 0 (8 KiB per wave); the next tile's first K-tile goes to buffer 1.
         const int next = FOLD ? ntiles : tile + (int)gridDim.x;       // the fold variant is launched one tile per workgroup
         const bool has_next = next < ntiles;
-        int m1 = 0, n1 = 0;
+        int m1 = m0, n1 = n0;                          // no next tile: KT_LAST re-reads this tile's first K-tile (harmless)
         if (has_next) origin(next, m1, n1);
-        const rsrc_t Ar1 = tile_rsrc(reinterpret_cast<const unsigned char*>(p.A) + (size_t)m1 * c.lda_b);
-        const rsrc_t Wr1 = tile_rsrc(reinterpret_cast<const unsigned char*>(p.W) + (size_t)n1 * c.ldw_b);
-        auto prefetch = [&]() {
-            if (has_next) {
-                unsigned char* b1 = lds + BUF_BYTES;
-                issue_piece(PA0, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
-                issue_piece(PW0, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
-                issue_piece(PW1, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
-                issue_piece(PA1, Ar1, Wr1, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, b1, wave);
-            }
-        };
+        c.aorg1 = (unsigned)m1 * c.lda_b; c.worg1 = (unsigned)n1 * c.ldw_b;
+
+        if (wm == 0) k_loop<true>(c, lds, acc, pb); else k_loop<false>(c, lds, acc, pb);
+
+        // every fragment read finished before the last barrier.  The buffer of the LAST K-tile is free for the epilogue's
+        // staging (8 KiB per wave); the other one already holds the next tile's first K-tile.
         if constexpr (FOLD) ln_apply<8>(fscr, acc, lane, fa, fb);
         const float4 no_pre[1] = {};
-        unsigned char* eraw = lds + wave * EPI_WAVE_BYTES;
+        unsigned char* eraw = lds + ((pb + c.nk - 1) & 1) * BUF_BYTES + wave * EPI_WAVE_BYTES;
         const int mw = m0 + wm * 128, nw = n0 + wn * 64;
         if constexpr (EPI == EPI_STD && sizeof(OutT) == 4) {
-            // residual variants load through the whole epilogue (pipelined residual rows): no early prefetch there
-            if (p.residual && p.xb_out) { wave_epilogue<EPI, OutT, 8, 1, true, 1, true>(p, acc, eraw, mw, nw, lane, no_pre); prefetch(); }
-            else if (p.residual) { wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, mw, nw, lane, no_pre); prefetch(); }
-            else wave_epilogue<EPI, OutT, 8, 1, true, 0, false>(p, acc, eraw, mw, nw, lane, no_pre, prefetch);
+            if (p.residual && p.xb_out) wave_epilogue<EPI, OutT, 8, 1, true, 1, true>(p, acc, eraw, mw, nw, lane, no_pre);
+            else if (p.residual) wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, mw, nw, lane, no_pre);
+            else wave_epilogue<EPI, OutT, 8, 1, true, 0, false>(p, acc, eraw, mw, nw, lane, no_pre);
         } else {
-            wave_epilogue<EPI, OutT, 8, 1, true, 0, false>(p, acc, eraw, mw, nw, lane, no_pre, prefetch);
+            wave_epilogue<EPI, OutT, 8, 1, true, 0, false>(p, acc, eraw, mw, nw, lane, no_pre);
         }
         if (!has_next) break;
-        // the 8 DMA instructions of the prefetch are older than every store issued after the hook (>= 8 per wave in every
-        // epilogue), and vmcnt retires in issue order: with at most 4 operations left in flight those are stores, i.e. the
-        // whole K-tile has landed, while the youngest stores keep draining under the next K loop
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                  // every wave is done staging through buffer 0; the K-tile is visible
+        __builtin_amdgcn_s_barrier();                  // every wave is done staging through the free buffer (the next K-tile 1 lands there)
         tile = next; m0 = m1; n0 = n1;
-        c.Ar = Ar1; c.Wr = Wr1;
-        pb = 1;
+        c.aorg = c.aorg1; c.worg = c.worg1;
+        pb = (pb + c.nk) & 1;
     }
 }
 
@@ -306,7 +323,8 @@ int launch256(const GemmParams& p0, hipStream_t s) {
 
 int pm_gemm256_supported(const GemmParams& p, int dtype, int epi, int out_dtype) {
     if (dtype != PMHIP_BF16) return 0;
-    if (p.M % BM || p.N % BN || p.K % KSTEP) return 0;
+    if (p.M % BM || p.N % BN || p.K % KSTEP || p.K < 2 * KSTEP) return 0;   // the streamed K loop peels a first and a last K-tile
+    if ((unsigned long long)p.M * p.lda * 2 >= (1ull << 31) || (unsigned long long)p.N * p.ldw * 2 >= (1ull << 31)) return 0;   // 32-bit buffer offsets   // the streamed K loop peels a first and a last K-tile
     if ((p.M / BM) * (p.N / BN) < 96) return 0;             // too few tiles: the small kernel has 4x the workgroups
     if (epi == EPI_STD && p.residual) {
         // residual GEMMs: the 128x128 kernel prefetches the residual tile and overlaps two workgroups per CU, which wins
