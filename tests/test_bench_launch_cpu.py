@@ -33,5 +33,5 @@ def test_single_rank_runs_in_process_and_forced_dist_spawns_one_child():
 def test_mismatched_world_size_is_an_error():
     e = dict(os.environ, WORLD_SIZE="3", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "launch-selftest", "--gpus", "2"],
-                       capture_output=True, text=True, timeout=120, env=e)
+                       capture_output=True, text=True, timeout=300, env=e)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

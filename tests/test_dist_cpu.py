@@ -68,15 +68,25 @@ def _free_port():
 def test_sharded_generate_matches_single_process(n_prompts):
     world = 2
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_prompts, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res, g = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    for attempt in range(2):                    # the port is probed, released and re-bound by the children: retry once on a lost race
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, n_prompts, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            res, g = q.get(timeout=300)         # a cold `import torch` in the children can take minutes
+        except Exception:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            if attempt == 1:
+                raise
+            continue
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        break
     single = FakePipe().generate([f"p{i}" for i in range(n_prompts)], seed=7, image_base=0, keep_on_device=True, timesteps=4,
                                  save_interval=2)
     assert len(res) == len(single)
