@@ -454,15 +454,41 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
     for (int qf = 0; qf < QF; ++qf) {      // cross-lane steps first, outside any divergent region
         inv[qf] = 1.0f / group4_sum(lrun[qf]);
     }
+    if constexpr (sizeof(T) == 2) {
+        // bf16: the wave's 64 output rows go through the (now idle) K / V^T ring, so that every global store instruction
+        // writes 8 whole 128-byte rows (non-temporal) instead of 16 x 4 pieces of 8 bytes at a row stride
+        constexpr int RS = 144;                                // staged row: 64 bf16 + pad, 16-B aligned, conflict-free
+        __syncthreads();                                       // every wave is done reading the ring
+        unsigned char* obuf = lds + wave * (64 * RS);
 #pragma unroll
-    for (int qf = 0; qf < QF; ++qf) {
-        const int q = q0 + qf * 16 + l15;
-        if (q < Nq) {
-            T* orow = out + ((size_t)b * Nq + q) * ldo + h * DH;
+        for (int qf = 0; qf < QF; ++qf)
 #pragma unroll
             for (int df = 0; df < 4; ++df)
-                store4(orow + df * 16 + g * 4, o[df][qf][0] * inv[qf], o[df][qf][1] * inv[qf],
-                       o[df][qf][2] * inv[qf], o[df][qf][3] * inv[qf]);
+                *reinterpret_cast<uint2*>(obuf + (qf * 16 + l15) * RS + (df * 16 + g * 4) * 2) =
+                    make_uint2(pack_bf16x2(o[df][qf][0] * inv[qf], o[df][qf][1] * inv[qf]), pack_bf16x2(o[df][qf][2] * inv[qf], o[df][qf][3] * inv[qf]));
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < QF * 2; ++it) {                  // 8 rows x 128 B per store instruction
+            const int r = it * 8 + (lane >> 3), c16 = lane & 7, q = q0 + r;
+            if (q < Nq) {
+                typedef unsigned nt_v4u __attribute__((ext_vector_type(4)));
+                const uint4 v = *reinterpret_cast<const uint4*>(obuf + r * RS + c16 * 16);
+                __builtin_nontemporal_store(nt_v4u{v.x, v.y, v.z, v.w},
+                                            reinterpret_cast<nt_v4u*>(out + ((size_t)b * Nq + q) * ldo + h * DH + c16 * 8));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            const int q = q0 + qf * 16 + l15;
+            if (q < Nq) {
+                T* orow = out + ((size_t)b * Nq + q) * ldo + h * DH;
+#pragma unroll
+                for (int df = 0; df < 4; ++df)
+                    store4(orow + df * 16 + g * 4, o[df][qf][0] * inv[qf], o[df][qf][1] * inv[qf],
+                           o[df][qf][2] * inv[qf], o[df][qf][3] * inv[qf]);
+            }
         }
     }
 }
@@ -479,7 +505,7 @@ extern "C" int pmhip_attention(int dtype, const void* Q, const void* K, const vo
     PM_REQUIRE(Q && K && Vt && out, "attention: null pointer");
     PM_REQUIRE(B > 0 && heads > 0 && Nq > 0 && Nkv > 0, "attention: empty problem");
     PM_REQUIRE(Nkv_pad % KT == 0 && Nkv_pad >= Nkv, "attention: Nkv_pad=%d must be a multiple of 64 >= Nkv=%d", Nkv_pad, Nkv);
-    PM_REQUIRE(ldo % 4 == 0, "attention: ldo must be a multiple of 4");
+    PM_REQUIRE(ldo % 4 == 0 && (dtype == PMHIP_F32 || ldo % 8 == 0), "attention: ldo must be a multiple of 4 (f32) / 8 (bf16: 16-byte row stores)");
     hipStream_t s = (hipStream_t)stream;
     dim3 block(THREADS);
     PmTimer tm(FAM_ATTENTION, s);

@@ -162,6 +162,18 @@ __device__ __forceinline__ void ln_apply(const float* scratch, f32x4_t (&acc)[MI
 // `hook` runs once, after the epilogue's own up-front loads (bias) have been waited for and before its first store: the
 // persistent 256x256 kernel issues the NEXT tile's first K-tile DMA there, so that no compiler-inserted wait for a load of
 // this epilogue can drain that DMA.
+
+// The epilogue's global stores are NON-TEMPORAL (`global_store_dwordx4 ... nt`): outputs are 64-200 MB per launch, far more
+// than the L2 holds, and are next read by a different kernel; measured on the whole bench (same box, tools/ab_same_box.sh):
+// GEMM family 98.7 -> 92.1 ms per step, head-split QKV 103 -> 98.5 us, SwiGLU 203 -> 190 us.
+typedef unsigned nt_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store16(void* p, uint4 v) {
+    __builtin_nontemporal_store(nt_v4u{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_v4u*>(p));
+}
+__device__ __forceinline__ void nt_store_row(float* p, const float (&v)[4]) { nt_store16(p, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]))); }
+__device__ __forceinline__ void nt_store_row(bf16_t* p, const float (&v)[8]) {
+    nt_store16(p, make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])));
+}
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 template <int EPI, typename OutT, int MI, int NPRE, bool FULL = false, int RES = -1, bool EMIT = false, typename Hook = NoHook>
@@ -201,7 +213,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {                             // 8 d-rows x 128 B per store instruction
                         const int d = it * 8 + (lane >> 3), c = (lane & 7) * 8;
-                        *reinterpret_cast<uint4*>(vrow + (size_t)d * p.tokens_pad + c) = *reinterpret_cast<const uint4*>(vbuf + d * 64 + c);
+                        nt_store16(vrow + (size_t)d * p.tokens_pad + c, *reinterpret_cast<const uint4*>(vbuf + d * 64 + c));
                     }
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -297,8 +309,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int erow = lane >> 2, q = lane & 3, m = mbase + erow;
             if (FULL || m < p.M)                                   // 4 lanes x 16 B = the row's 32 hidden columns
-                *reinterpret_cast<uint4*>(reinterpret_cast<OutT*>(p.out) + (size_t)m * p.ldo + (nw >> 1) + q * 8) =
-                    *reinterpret_cast<const uint4*>(eraw + erow * RS + q * 16);
+                nt_store16(reinterpret_cast<OutT*>(p.out) + (size_t)m * p.ldo + (nw >> 1) + q * 8, *reinterpret_cast<const uint4*>(eraw + erow * RS + q * 16));
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             continue;
@@ -323,8 +334,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                 const int r = it * 8 + (lane >> 3), mm = mbase + r, c16 = lane & 7;
                 if (FULL || mm < p.M) {
                     const int b = mm / p.tokens, t = mm % p.tokens;
-                    *reinterpret_cast<uint4*>(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + c16 * 8) =
-                        *reinterpret_cast<const uint4*>(eraw + r * RS + c16 * 16);
+                    nt_store16(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + c16 * 8, *reinterpret_cast<const uint4*>(eraw + r * RS + c16 * 16));
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -358,7 +368,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                             v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                         }
                     }
-                    store_row(reinterpret_cast<OutT*>(p.out) + (size_t)mm * p.ldo + ncol, v);
+                    nt_store_row(reinterpret_cast<OutT*>(p.out) + (size_t)mm * p.ldo + ncol, v);
                     if constexpr (EMIT && sizeof(OutT) == 4) {
                         // LayerNorm fold: the consumer GEMM reads this row as bf16; its statistics come from the f32 values
                         store4(p.xb_out + (size_t)mm * p.ldxb + ncol, v[0], v[1], v[2], v[3]);
@@ -416,7 +426,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                         const float4 t4 = *reinterpret_cast<const float4*>(ebuf + r * ESTRIDE + ccol + j);
                         v[j] = t4.x * sc; v[j + 1] = t4.y * sc; v[j + 2] = t4.z * sc; v[j + 3] = t4.w * sc;
                     }
-                    store_row(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + ccol, v);
+                    nt_store_row(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + ccol, v);
                 }
             }
         }
