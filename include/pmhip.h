@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PMHIP_ABI_VERSION 3
+#define PMHIP_ABI_VERSION 4
 
 enum { PMHIP_OK = 0, PMHIP_EINVAL = 1, PMHIP_EHIP = 2, PMHIP_ENOMEM = 3, PMHIP_ESTATE = 4 };
 enum { PMHIP_F32 = 0, PMHIP_BF16 = 1 };
@@ -80,6 +80,8 @@ typedef struct pmhip_lnfold {
     const float* c;       /* [N]: sum_k of the (rounded) gamma-scaled weight row */
     const float* d;       /* [N]: sum_k beta[k] * W[n,k] */
     float eps;            /* LayerNorm eps */
+    float* coef;          /* scratch [M][2]: the consumer entry point reduces `stats` to (rstd, -rstd * mean) per row here (one
+                             small kernel, chunk order: deterministic) before its GEMM */
 } pmhip_lnfold;
 
 /* pmhip_gemm with an f32 result that ALSO emits xb_out[M,N] (bf16 copy, row stride ldxb) and stats_out[N/64][M][2].

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpaintmind_hip.so")
 PMHIP_OK = 0
 F32, BF16 = 0, 1
 PART_Q, PART_K, PART_V = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 vp = C.c_void_p
 i32 = C.c_int
@@ -60,7 +60,7 @@ class S2Weights(C.Structure):
 
 class LnFold(C.Structure):
     """mirror of pmhip_lnfold"""
-    _fields_ = [("stats", vp), ("c", vp), ("d", vp), ("eps", f32)]
+    _fields_ = [("stats", vp), ("c", vp), ("d", vp), ("eps", f32), ("coef", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/pmhip.h declares

@@ -146,6 +146,7 @@ struct TowerBufs {
     void* attn = nullptr;   // T [M, inner]
     void* hid = nullptr;    // T [M, hidden_pad]
     float* split = nullptr; // dim_head != 64 only: f32 scratch of the plain head-split path [M, 3*inner]
+    float* coef = nullptr;  // LayerNorm fold: per-row (rstd, -rstd * mean) scratch of the consumer
     float* stats = nullptr; // LayerNorm fold: per row and 64-column chunk (sum x, sum x^2) of the residual stream
     // LayerNorm fold state of one forward pass.  fold: the handle is in bf16 mode and folding is enabled; stats_valid:
     // `stats` and the bf16 copy of x (kept in `y`) describe the CURRENT x (its producer was a GEMM that emitted them)
@@ -183,6 +184,7 @@ int alloc_tower(Workspace& ws, const char* tag, int dtype, const pmhip_tower_cfg
     WS(ws, (t + ".attn").c_str(), M * inner * es, b.attn);
     WS(ws, (t + ".hid").c_str(), M * tc.hidden_pad * es, b.hid);
     WS(ws, (t + ".stats").c_str(), M * (tc.dim / 64) * 2 * 4, b.stats);
+    WS(ws, (t + ".coef").c_str(), M * 2 * 4, b.coef);
     b.split = nullptr;
     if (dh != 64) WS(ws, (t + ".split").c_str(), M * 3 * inner * 4, b.split);
     b.fold = dtype == PMHIP_BF16 && dh == 64 && ln_fold_enabled();
@@ -208,7 +210,7 @@ int ln_heads(int dtype, TowerBufs& b, const float* g, const float* be, const voi
              int M, int dim, int heads, int dh, int tokens, int Np, int nparts, const int* kinds, void* const* outs, float q_scale,
              hipStream_t s) {
     if (b.fold && b.stats_valid && Wf && pmhip_lnfold_supported(dtype, 2, M, nparts * heads * 64, dim)) {
-        const pmhip_lnfold ln{b.stats, fc, fd, 1e-5f};
+        const pmhip_lnfold ln{b.stats, fc, fd, 1e-5f, b.coef};
         return pmhip_gemm_heads_ln(dtype, b.y, dim, Wf, dim, M, dim, heads, tokens, Np, nparts, kinds, outs, q_scale, &ln, s);
     }
     PM_TRY(pmhip_layernorm(b.x, g, be, 1e-5f, b.y, dtype, M, dim, s));
@@ -254,7 +256,7 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
 
     // x = ffnet(norm(x)) + x
     if (b.fold && b.stats_valid && L.w12p_f && pmhip_lnfold_supported(dtype, 1, M, 2 * tc.hidden_pad, dim)) {
-        const pmhip_lnfold ln{b.stats, L.w12_c, L.w12_d, eps};
+        const pmhip_lnfold ln{b.stats, L.w12_c, L.w12_d, eps, b.coef};
         PM_TRY(pmhip_gemm_swiglu_ln(dtype, b.y, dim, L.w12p_f, L.b12p, b.hid, tc.hidden_pad, M, tc.hidden_pad, dim, &ln, s));
     } else {
         PM_TRY(pmhip_layernorm(b.x, L.ln2_g, L.ln2_b, eps, b.y, dtype, M, dim, s));
@@ -524,7 +526,7 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s) {
     for (int l = 0; l < c.tower.depth; ++l)
         PM_TRY(layer_forward(h->dtype, h->layers[l], c.tower, tb, B, c.tokens, true, &h->cross[l], s));
     if (tb.fold && tb.stats_valid && h->w.logits_wf && pmhip_lnfold_supported(h->dtype, 0, M, c.n_embed, dim)) {
-        const pmhip_lnfold ln{tb.stats, h->w.logits_c, h->w.logits_d, 1e-5f};      // the final norm folded into to_logits
+        const pmhip_lnfold ln{tb.stats, h->w.logits_c, h->w.logits_d, 1e-5f, tb.coef};      // the final norm folded into to_logits
         return pmhip_gemm_ln(h->dtype, tb.y, dim, h->w.logits_wf, dim, h->w.logits_b, logits, c.n_embed, PMHIP_F32, M, c.n_embed, dim,
                              &ln, s);
     }

@@ -182,10 +182,10 @@ namespace {
 // LayerNorm fold (gemm_common.h): checks shared by the three consumer entry points; fills the consumer fields
 int set_lnfold(GemmParams& p, const pmhip_lnfold* ln, int dtype, int epi, int out_dtype) {
     if (!ln) return PMHIP_OK;
-    PM_REQUIRE(ln->stats && ln->c && ln->d, "gemm_ln: null fold pointer");
+    PM_REQUIRE(ln->stats && ln->c && ln->d && ln->coef, "gemm_ln: null fold pointer");
     PM_REQUIRE(dtype == PMHIP_BF16, "gemm_ln: the LayerNorm fold exists in bf16 mode only");
     PM_REQUIRE(p.K % 128 == 0, "gemm_ln: K=%d must be a multiple of 128", p.K);
-    p.ln_stats = ln->stats; p.ln_c = ln->c; p.ln_d = ln->d; p.ln_eps = ln->eps; p.ln_nc = p.K / 64;
+    p.ln_stats = ln->stats; p.ln_c = ln->c; p.ln_d = ln->d; p.ln_eps = ln->eps; p.ln_nc = p.K / 64; p.ln_coef = ln->coef;
     PM_REQUIRE(pm_gemm256_supported(p, dtype, epi, out_dtype), "gemm_ln: shape M=%d N=%d K=%d is not served by the 256x256 kernel", p.M, p.N, p.K);
     return PMHIP_OK;
 }
@@ -211,7 +211,10 @@ int gemm_impl(int dtype, const void* A, int lda, const void* W, int ldw, const f
     }
     PM_TRY(set_lnfold(p, ln, dtype, EPI_STD, out_dtype));
     hipStream_t s = (hipStream_t)stream;
-    if (ln) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
+    if (ln) {
+        PM_TRY(pm_ln_finalize(p.ln_stats, p.ln_nc, p.M, p.ln_eps, ln->coef, stream));
+        return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
+    }
     if (use2b(p, dtype, EPI_STD, out_dtype)) return pm_gemm2b_launch(p, EPI_STD, out_dtype, s);
     if (use256(p, dtype, EPI_STD, out_dtype)) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_STD, float>(p, s);
@@ -257,7 +260,10 @@ static int gemm_swiglu_impl(int dtype, const void* A, int lda, const void* W12p,
     PM_REQUIRE(b12p && out && ldo % 8 == 0, "gemm_swiglu: bias/out required, ldo multiple of 8");
     PM_TRY(set_lnfold(p, ln, dtype, EPI_SWIGLU, dtype));
     hipStream_t s = (hipStream_t)stream;
-    if (ln) return pm_gemm256_launch(p, EPI_SWIGLU, dtype, s);
+    if (ln) {
+        PM_TRY(pm_ln_finalize(p.ln_stats, p.ln_nc, p.M, p.ln_eps, ln->coef, stream));
+        return pm_gemm256_launch(p, EPI_SWIGLU, dtype, s);
+    }
     if (use2b(p, dtype, EPI_SWIGLU, dtype)) return pm_gemm2b_launch(p, EPI_SWIGLU, dtype, s);
     if (use256(p, dtype, EPI_SWIGLU, dtype)) return pm_gemm256_launch(p, EPI_SWIGLU, dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_SWIGLU, float>(p, s);
@@ -295,7 +301,10 @@ static int gemm_heads_impl(int dtype, const void* A, int lda, const void* W, int
     PM_TRY(check_common(p, dtype));
     PM_TRY(set_lnfold(p, ln, dtype, EPI_HEADS, dtype));
     hipStream_t s = (hipStream_t)stream;
-    if (ln) return pm_gemm256_launch(p, EPI_HEADS, dtype, s);
+    if (ln) {
+        PM_TRY(pm_ln_finalize(p.ln_stats, p.ln_nc, p.M, p.ln_eps, ln->coef, stream));
+        return pm_gemm256_launch(p, EPI_HEADS, dtype, s);
+    }
     if (use2b(p, dtype, EPI_HEADS, dtype)) return pm_gemm2b_launch(p, EPI_HEADS, dtype, s);
     if (use256(p, dtype, EPI_HEADS, dtype)) return pm_gemm256_launch(p, EPI_HEADS, dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_HEADS, float>(p, s);

@@ -77,6 +77,7 @@ struct LoopCtx {
     unsigned fa0, fa1, fw0, fw1;                        // per-lane fragment read offsets (kk = 0, 1)
     unsigned lds_base;                                  // LDS byte address of the staging buffers
     int nk, wave;
+    int mw, nw, lane;                                   // first row / column of this wave in the current tile (LayerNorm fold)
 };
 
 
@@ -130,9 +131,12 @@ enum { KT_STEADY = 0, KT_FIRST = 1, KT_LAST = 2 };
 // reads of the wave's read slot, i.e. while the other wave of the SIMD runs MFMAs (behind the wave's own MFMAs it measured
 // 2-5 % slower).  LEAD = true: waves with wm = 0 ({reads | MFMAs}); LEAD = false: waves with wm = 1, one slot behind
 // ({MFMAs of the previous phase | reads}).  Both roles execute the SAME sequence of barriers, DMA issues and vmcnt waits.
-template <bool LEAD, int KIND>
-__device__ __forceinline__ void k_tile(const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], uint4 (&a)[4][2], uint4 (&w)[2][2],
-                                       int kt, int pb) {
+template <bool LEAD, int KIND, bool FOLD>
+__device__ __forceinline__ void k_tile(const GemmParams& p, const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], uint4 (&a)[4][2],
+                                       uint4 (&w)[2][2], LnCoef& lnc, int kt, int pb) {
+    // LayerNorm fold: the tile's per-row coefficients are loaded in the first read slot of its LAST K-tile (LN_COEF_LOADS more
+    // operations in flight through phases 1 and 2, older than the phase's DMA) and are retired by the closing vmcnt(0)
+    constexpr int XL = (FOLD && KIND == KT_LAST) ? LN_COEF_LOADS : 0;
     constexpr bool FIRST = KIND == KT_FIRST;
     constexpr bool ONE_PER_PHASE = KIND != KT_LAST;
     const unsigned boff = (unsigned)((kt + pb) & 1) * BUF_BYTES;   // LDS byte addresses of this K-tile's fragments (pb: buffer of K-tile 0)
@@ -146,14 +150,17 @@ __device__ __forceinline__ void k_tile(const LoopCtx& c, unsigned char* lds, f32
         if constexpr (phase == 1) { ISSUE(PA0) } else if constexpr (phase == 2) { ISSUE(PW0) }                       \
         else if constexpr (phase == 3) { ISSUE(PW1) } else { ISSUE(PA1) }                                            \
     } else {                                                                                                         \
+        if constexpr (phase == 1 && FOLD) ln_coef_issue(p, c.mw, c.nw, c.lane, lnc);                                 \
         if constexpr (phase == 1) { ISSUE_NEXT_TILE(PA0) ISSUE_NEXT_TILE(PW0) }                                      \
         else if constexpr (phase == 2) { ISSUE_NEXT_TILE(PW1) ISSUE_NEXT_TILE(PA1) }                                 \
     }
 #define WAIT(phase)                                                                                                  \
     if constexpr (KIND == KT_STEADY) VMW(4)                                                                          \
     else if constexpr (KIND == KT_FIRST) { if constexpr (phase == 4) VMW(4) }                                        \
-    else {                                                                                                           \
+    else if constexpr (XL == 0) {                                                                                    \
         if constexpr (phase == 1) VMW(6) else if constexpr (phase == 2) VMW(8) else if constexpr (phase == 4) VMW(0) \
+    } else {                                                                                                         \
+        if constexpr (phase == 1) VMW(15) else if constexpr (phase == 2) VMW(17) else if constexpr (phase == 4) VMW(0) \
     }
     // ---------------- phase 1: A rows [0,64) x W rows [0,32)
     if constexpr (LEAD) { RD_A(0) RD_W(0) DMA(1) } else if constexpr (!FIRST) { LGKM0; MMA(1, 0) }
@@ -186,12 +193,12 @@ __device__ __forceinline__ void k_tile(const LoopCtx& c, unsigned char* lds, f32
 }
 
 // The K loop of one output tile for one wave: straight-line K-tiles, the first and the last peeled (nk >= 2).
-template <bool LEAD>
-__device__ __forceinline__ void k_loop(const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], int pb) {
+template <bool LEAD, bool FOLD>
+__device__ __forceinline__ void k_loop(const GemmParams& p, const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], LnCoef& lnc, int pb) {
     uint4 a[4][2], w[2][2];                        // [fragment][kk]
-    k_tile<LEAD, KT_FIRST>(c, lds, acc, a, w, 0, pb);
-    for (int kt = 1; kt + 1 < c.nk; ++kt) k_tile<LEAD, KT_STEADY>(c, lds, acc, a, w, kt, pb);
-    k_tile<LEAD, KT_LAST>(c, lds, acc, a, w, c.nk - 1, pb);
+    k_tile<LEAD, KT_FIRST, FOLD>(p, c, lds, acc, a, w, lnc, 0, pb);
+    for (int kt = 1; kt + 1 < c.nk; ++kt) k_tile<LEAD, KT_STEADY, FOLD>(p, c, lds, acc, a, w, lnc, kt, pb);
+    k_tile<LEAD, KT_LAST, FOLD>(p, c, lds, acc, a, w, lnc, c.nk - 1, pb);
     if constexpr (!LEAD) { LGKM0; MMA(1, 0) }
 }
 #undef DSR
@@ -249,15 +256,12 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     c.aorg = (unsigned)m0 * c.lda_b; c.worg = (unsigned)n0 * c.ldw_b;
 
     // prologue of the FIRST tile: its whole first K-tile
-    LnLoads lnl;
-    if constexpr (FOLD) ln_stats_issue(p, m0 + wm * 128, n0 + wn * 64, lane, lnl);      // before the DMA: these return first
     issue_piece(PA0, c.Ar, c.Wr, c.aorg, c.worg, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     issue_piece(PW0, c.Ar, c.Wr, c.aorg, c.worg, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     issue_piece(PW1, c.Ar, c.Wr, c.aorg, c.worg, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
     issue_piece(PA1, c.Ar, c.Wr, c.aorg, c.worg, c.lda_b, c.ldw_b, c.laneoffA, c.laneoffW, 0, lds, wave);
-    float fa[FOLD ? 8 : 1], fb[FOLD ? 8 : 1];
     float* fscr = reinterpret_cast<float*>(lds + 2 * BUF_BYTES + (FOLD ? wave * 2048 : 0));
-    if constexpr (FOLD) ln_row_coeffs<8>(p, lane, fscr, lnl, fa, fb);        // 4 pieces x 2 DMA instructions stay in flight
+    c.lane = lane;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the whole first K-tile (KT_FIRST takes no waits for it)
     __builtin_amdgcn_s_barrier();
 
@@ -269,17 +273,23 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-        const int next = FOLD ? ntiles : tile + (int)gridDim.x;       // the fold variant is launched one tile per workgroup
+        const int next = tile + (int)gridDim.x;
         const bool has_next = next < ntiles;
         int m1 = m0, n1 = n0;                          // no next tile: KT_LAST re-reads this tile's first K-tile (harmless)
         if (has_next) origin(next, m1, n1);
         c.aorg1 = (unsigned)m1 * c.lda_b; c.worg1 = (unsigned)n1 * c.ldw_b;
 
-        if (wm == 0) k_loop<true>(c, lds, acc, pb); else k_loop<false>(c, lds, acc, pb);
+        c.mw = m0 + wm * 128; c.nw = n0 + wn * 64;
+        LnCoef lnc;
+        if (wm == 0) k_loop<true, FOLD>(p, c, lds, acc, lnc, pb); else k_loop<false, FOLD>(p, c, lds, acc, lnc, pb);
 
         // every fragment read finished before the last barrier.  The buffer of the LAST K-tile is free for the epilogue's
         // staging (8 KiB per wave); the other one already holds the next tile's first K-tile.
-        if constexpr (FOLD) ln_apply<8>(fscr, acc, lane, fa, fb);
+        if constexpr (FOLD) {
+            float fa[8], fb[8];
+            ln_coef_finish(lane, fscr, lnc, fa, fb);
+            ln_apply<8>(fscr, acc, lane, fa, fb);
+        }
         const float4 no_pre[1] = {};
         unsigned char* eraw = lds + ((pb + c.nk - 1) & 1) * BUF_BYTES + wave * EPI_WAVE_BYTES;
         const int mw = m0 + wm * 128, nw = n0 + wn * 64;
@@ -313,7 +323,7 @@ int launch256(const GemmParams& p0, hipStream_t s) {
     if (persist < 0) { const char* e = getenv("PMHIP_PERSIST256"); persist = e ? atoi(e) : 256; }
     const int grid = (persist > 0 && tiles > persist) ? persist : tiles;
     PmTimer tm(FAM_GEMM, s);
-    if (p.ln_stats) hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, true>), dim3(tiles), dim3(THREADS), 0, s, p);
+    if (p.ln_coef) hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, true>), dim3(grid), dim3(THREADS), 0, s, p);
     else hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, false>), dim3(grid), dim3(THREADS), 0, s, p);
     PM_HIP(hipGetLastError());
     return PMHIP_OK;

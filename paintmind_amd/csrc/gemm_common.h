@@ -31,6 +31,7 @@ struct GemmParams {
     // LayerNorm fold, consumer side (256x256 kernel): A is the RAW bf16 row, W carries gamma, and the epilogue applies
     // out = rstd * acc - rstd * mean * c[n] + d[n] with (mean, rstd) from the producer's partial sums
     const float* ln_stats; int ln_nc;              // [ln_nc][M][2], ln_nc = K / 64
+    const float* ln_coef;                          // [M][2]: (rstd, -rstd * mean), reduced from ln_stats by pm_ln_finalize
     const float* ln_c; const float* ln_d;          // [N]: c = sum_k bf16(gamma_k W_nk), d = sum_k beta_k W_nk
     float ln_eps;
 };
@@ -79,6 +80,28 @@ __device__ __forceinline__ float silu_mul(float x1, float x2, int fast) {
 // The loads are inline asm: hipcc would otherwise wait vmcnt(0) -- draining the LDS-DMA of the first K-tile that is in
 // flight at the same time -- before their first use.  ln_stats_issue goes BEFORE the DMA pieces are issued,
 // ln_row_coeffs after them with `dma_in_flight` = the number of DMA instructions issued in between (counted wait).
+// Round 2, second version: the consumer reads the per-row pair (rstd, -rstd * mean) that pm_ln_finalize reduced from the
+// partial sums -- 8 eight-byte loads per lane plus one for c | d, issued (inline asm, invisible to hipcc's waits) in the
+// first read slot of the tile's LAST K-tile and retired by that K-tile's closing vmcnt(0), so the fold costs the persistent,
+// streamed K loop nothing but 20 registers in its last K-tile.
+struct LnCoef { float2 ab[8]; f32x4_t cd; };
+__device__ __forceinline__ void ln_coef_issue(const GemmParams& p, int mwave, int nw, int lane, LnCoef& L) {
+    const float* a = p.ln_coef + ((size_t)mwave + (lane & 15)) * 2;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(L.ab[mi]) : "v"(a + mi * 32) : "memory");
+    const float* cda = (lane < 16 ? p.ln_c : p.ln_d) + nw + (lane & 15) * 4;      // lanes >= 32 re-read lanes 0-31's addresses
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(L.cd) : "v"(cda) : "memory");
+}
+constexpr int LN_COEF_LOADS = 9;
+// after the loads have been waited for: c | d go through the wave's LDS scratch (ln_apply reads them from there)
+__device__ __forceinline__ void ln_coef_finish(int lane, float* scratch, LnCoef& L, float (&fa)[8], float (&fb)[8]) {
+    if (lane < 32) *reinterpret_cast<f32x4_t*>(scratch + 256 + lane * 4) = L.cd;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) { fa[mi] = L.ab[mi].x; fb[mi] = L.ab[mi].y; }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 constexpr int LN_MAXC = 16;
 struct LnLoads { f32x4_t t[LN_MAXC]; f32x4_t cd; };
 

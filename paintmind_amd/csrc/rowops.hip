@@ -193,6 +193,32 @@ inline int grid_for(size_t total) {
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ stats, int nc, int M, float eps, float2* __restrict__ coef) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < nc; ++c) {                              // chunk order: deterministic
+        const float2 t = *reinterpret_cast<const float2*>(stats + ((size_t)c * M + m) * 2);
+        s1 += t.x; s2 += t.y;
+    }
+    const float invD = 1.0f / (float)(nc * 64);
+    const float mean = s1 * invD;
+    const float var = fmaxf(s2 * invD - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    coef[m] = make_float2(rstd, -rstd * mean);
+}
+}  // namespace
+
+int pm_ln_finalize(const float* stats, int nc, int M, float eps, float* coef, pmhip_stream stream) {
+    PM_REQUIRE(stats && coef && nc > 0 && M > 0, "ln_finalize: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    PmTimer tm(FAM_ROWOPS, s);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stats, nc, M, eps, reinterpret_cast<float2*>(coef));
+    PM_HIP(hipGetLastError());
+    return PMHIP_OK;
+}
+
 extern "C" int pmhip_layernorm(const float* x, const float* gamma, const float* beta, float eps, void* out,
                                int out_dtype, int M, int D, pmhip_stream stream) {
     PM_REQUIRE(x && gamma && beta && out, "layernorm: null pointer");

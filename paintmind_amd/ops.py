@@ -135,6 +135,9 @@ def gemm_stats(a, w, bias=None, residual=None, res_rows=0):
 def _lnfold(stats, c, d, eps):
     ln = _lib.LnFold()
     ln.stats, ln.c, ln.d, ln.eps = C.c_void_p(stats.data_ptr()), C.c_void_p(c.data_ptr()), C.c_void_p(d.data_ptr()), float(eps)
+    coef = torch.empty(stats.shape[1], 2, device=stats.device, dtype=torch.float32)     # scratch: (rstd, -rstd * mean) per row
+    ln.coef = C.c_void_p(coef.data_ptr())
+    ln._keep = coef
     return ln
 
 
