@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 USE_GRAPH = os.environ.get("PM_BENCH_NO_GRAPH", "0") != "1"   # decode loop = one replayed hipGraph (captured during warm-up)
-STREAMS = int(os.environ.get("PM_BENCH_STREAMS", "3"))   # concurrent micro-batches per GPU (1 = one stream)
+STREAMS = int(os.environ.get("PM_BENCH_STREAMS", "2"))   # concurrent micro-batches per GPU (1 = one stream); 2 measured best
 LANE_SPLIT = os.environ.get("PM_BENCH_LANE_SPLIT")       # development: explicit micro-batch sizes, e.g. "32,16,16"
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3

@@ -225,6 +225,10 @@ class Pipeline(nn.Module):
         else:
             streams = max(1, min(int(streams), B))
             bounds = None
+            if streams == 2 and B >= 8:
+                # two lanes of EQUAL size run the same kernel sequence in lockstep and meet in the same (MFMA- or HBM-bound)
+                # kernel all the time; one image of difference lets them drift apart (measured: 445-447 -> 450-453 images/s)
+                bounds = [(0, B // 2 + 1), (B // 2 + 1, B)]
         if streams == 1:
             ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
             return eng.generate(self.vqgan.engine(), ids, context, temps, nmask, decode_flags, topk, seed=seed,
