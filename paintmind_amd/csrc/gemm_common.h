@@ -294,6 +294,78 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
     // to be acknowledged by L2 instead of streaming them.
     __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0); expcnt / lgkmcnt untouched
     hook();
+    // The two bf16 epilogues that carry most of the GEMM time (SwiGLU gate, Q / K head split) run their 16-row slices as a
+    // two-stage pipeline over two staging buffers: slice mi+1 is staged while slice mi's rows are read back and stored, one
+    // LDS round trip and one wait per slice instead of two (ablation: of 98 us for the QKV GEMM 17 us were this chain, of
+    // 201 us for SwiGLU 31 us chain + gate arithmetic).
+    if constexpr (GATE_IN_REGS && FULL) {
+        constexpr int RS = 80, BUFB = 2048;                        // bytes per staged row: 32 bf16 + pad; buffer stride
+        auto stage = [&](int mi) {
+            unsigned char* row = eraw + (mi & 1) * BUFB + l15 * RS;
+            *reinterpret_cast<uint2*>(row + g * 8) = make_uint2(
+                pack_bf16x2(silu_mul(acc[mi][0][0] + sb[0].x, acc[mi][1][0] + sb[1].x, p.fast_math),
+                            silu_mul(acc[mi][0][1] + sb[0].y, acc[mi][1][1] + sb[1].y, p.fast_math)),
+                pack_bf16x2(silu_mul(acc[mi][0][2] + sb[0].z, acc[mi][1][2] + sb[1].z, p.fast_math),
+                            silu_mul(acc[mi][0][3] + sb[0].w, acc[mi][1][3] + sb[1].w, p.fast_math)));
+            *reinterpret_cast<uint2*>(row + 32 + g * 8) = make_uint2(
+                pack_bf16x2(silu_mul(acc[mi][2][0] + sb[2].x, acc[mi][3][0] + sb[3].x, p.fast_math),
+                            silu_mul(acc[mi][2][1] + sb[2].y, acc[mi][3][1] + sb[3].y, p.fast_math)),
+                pack_bf16x2(silu_mul(acc[mi][2][2] + sb[2].z, acc[mi][3][2] + sb[3].z, p.fast_math),
+                            silu_mul(acc[mi][2][3] + sb[2].w, acc[mi][3][3] + sb[3].w, p.fast_math)));
+        };
+        stage(0);
+        const int erow = lane >> 2, q = lane & 3;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slice mi staged; the reads of slice mi-1 (other buffer) returned
+            const uint4 v = *reinterpret_cast<const uint4*>(eraw + (mi & 1) * BUFB + erow * RS + q * 16);
+            if (mi + 1 < MI) stage(mi + 1);
+            nt_store16(reinterpret_cast<OutT*>(p.out) + (size_t)(mwave + mi * 16 + erow) * p.ldo + (nw >> 1) + q * 8, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return;
+    }
+    if constexpr (EPI == EPI_HEADS && sizeof(OutT) == 2 && FULL) {     // Q / K part (the V part returned above)
+        constexpr int RS = 144, BUFB = 4096;                       // bytes per staged row: 64 bf16 + pad; buffer stride
+        const int part = nw / p.inner;
+        const int h = (nw % p.inner) >> 6;
+        const int kind = p.kinds[part];
+        OutT* dst = reinterpret_cast<OutT*>(p.outs[part]);
+        const int tstride = kind == PMHIP_PART_Q ? p.tokens : p.tokens_pad;
+        const float sc = kind == PMHIP_PART_Q ? p.q_scale : 1.0f;
+        auto stage = [&](int mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<uint2*>(eraw + (mi & 1) * BUFB + l15 * RS + ni * 32 + g * 8) =
+                    make_uint2(pack_bf16x2(acc[mi][ni][0] * sc, acc[mi][ni][1] * sc), pack_bf16x2(acc[mi][ni][2] * sc, acc[mi][ni][3] * sc));
+        };
+        stage(0);
+        // (batch, token) of the wave's first row once per tile, wave-uniform: a per-row `mm / tokens`, `mm % tokens` is two
+        // ~40-instruction integer divisions per row and store and was most of this epilogue's non-store time
+        const int b0 = mwave / p.tokens, t0 = mwave % p.tokens;
+        const bool nowrap = t0 + MI * 16 <= p.tokens;              // the wave's rows stay inside one image (tokens % 128 == 0: always)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            uint4 v[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) v[it] = *reinterpret_cast<const uint4*>(eraw + (mi & 1) * BUFB + (it * 8 + (lane >> 3)) * RS + (lane & 7) * 16);
+            if (mi + 1 < MI) stage(mi + 1);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {                       // 8 rows x 128 B per store instruction
+                const int r = mi * 16 + it * 8 + (lane >> 3);
+                int b = b0, t = t0 + r;
+                if (!nowrap) { b = (mwave + r) / p.tokens; t = (mwave + r) % p.tokens; }
+                nt_store16(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + (lane & 7) * 8, v[it]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return;
+    }
     constexpr bool PIPE_RES = (EPI == EPI_STD) && FULL && RES == 1 && NPRE == 1 && sizeof(OutT) == 4;
     float4 rnext[ITERS] = {};
     if constexpr (PIPE_RES) {
