@@ -399,3 +399,36 @@ def test_masked_ce_nothing_masked_is_nan_and_bad_args_raise():
         ops.masked_ce(logits, labels, torch.zeros(8, device=dev()), 1.5)
     with pytest.raises(PmhipError):
         ops.random_mask(torch.zeros(1, 8, 4, device=dev()), torch.zeros(1, 8, device=dev()), torch.zeros(4, device=dev()), 9)
+
+
+@pytest.mark.parametrize("M,N,K", [(19200, 1024, 128), (65792, 256, 192), (8192, 3072, 320)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_large_tile_kernel_streamed_tiles(M, N, K, out_dtype):
+    """The persistent 256x256 kernel streams the K-tiles of consecutive output tiles as one DMA sequence: tile counts that do
+    not divide by the number of workgroups (300, 257 = one workgroup with two tiles, 384) and short K loops (2, 3 and 5 K-tiles:
+    first + last only, one steady tile, an odd count so that the buffer parity flips from tile to tile)."""
+    a, w, b = bf16_round(rnd(M, K)), bf16_round(rnd(N, K, scale=K ** -0.5)), rnd(N)
+    ref = a @ w.T + b
+    for _ in range(2):                                   # twice: the second launch finds warm caches / another timing
+        out = n(ops.gemm(t(a, torch.bfloat16), t(w, torch.bfloat16), bias=t(b), out_dtype=out_dtype))
+        assert rel_err(out, ref) < (2e-5 if out_dtype == torch.float32 else 1e-2), rel_err(out, ref)
+        blk = np.abs(out - ref).reshape(M // 256, 256, N // 256, 256).max(axis=(1, 3))
+        assert blk.max() < (1e-3 if out_dtype == torch.float32 else 0.15 * np.abs(ref).max())
+
+
+def test_gemm_large_tile_kernel_streamed_residual_and_ragged_heads():
+    """(a) residual f32 GEMM on the 256x256 kernel with 150 tiles (K = 1024); (b) head split with 336 tokens per image (padded to 384): the
+    wave's 128 rows straddle images, so the Q / K epilogue takes its per-row (batch, token) path and V its scalar path."""
+    M, N, K = 19200, 512, 1024
+    a, w, b, r = bf16_round(rnd(M, K)), bf16_round(rnd(N, K, scale=K ** -0.5)), rnd(N), rnd(M, N)
+    out = n(ops.gemm(t(a, torch.bfloat16), t(w, torch.bfloat16), bias=t(b), residual=t(r), out_dtype=torch.float32))
+    assert rel_err(out, a @ w.T + b + r) < 2e-5
+    B, heads, N_tok, D = 64, 8, 336, 512
+    x = bf16_round(rnd(B * N_tok, D))
+    wqkv = bf16_round(rnd(3 * heads * 64, D, scale=D ** -0.5))
+    q, k, vt = ops.gemm_heads(t(x, torch.bfloat16), t(wqkv, torch.bfloat16), heads, N_tok, [ops.PART_Q, ops.PART_K, ops.PART_V], 0.125)
+    full = (x @ wqkv.T).reshape(B, N_tok, 3, heads, 64)
+    assert rel_err(n(q), full[:, :, 0].transpose(0, 2, 1, 3) * 0.125) < 1e-2
+    assert rel_err(n(k)[:, :, :N_tok], full[:, :, 1].transpose(0, 2, 1, 3)) < 1e-2
+    assert rel_err(n(vt)[:, :, :, :N_tok], full[:, :, 2].transpose(0, 2, 3, 1)) < 1e-2
+    assert float(k[:, :, N_tok:].abs().max()) == 0 and float(vt[:, :, :, N_tok:].abs().max()) == 0
