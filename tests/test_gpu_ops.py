@@ -432,3 +432,27 @@ def test_gemm_large_tile_kernel_streamed_residual_and_ragged_heads():
     assert rel_err(n(k)[:, :, :N_tok], full[:, :, 1].transpose(0, 2, 1, 3)) < 1e-2
     assert rel_err(n(vt)[:, :, :, :N_tok], full[:, :, 2].transpose(0, 2, 3, 1)) < 1e-2
     assert float(k[:, :, N_tok:].abs().max()) == 0 and float(vt[:, :, :, N_tok:].abs().max()) == 0
+
+
+def test_streamed_kernels_are_bit_stable_over_repetitions():
+    """Race screen for the hand-placed waits (counted vmcnt / lgkmcnt, inline-asm LDS reads) of gemm256 and attention: 150
+    launches each at the bench shapes, other kernels in between, must all produce the bits of the first launch."""
+    g = torch.Generator().manual_seed(7)
+    M, D = 65536, 512
+    a = (torch.randn(M, D, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    wq = (torch.randn(1536, D, generator=g) * D ** -0.5).to(torch.bfloat16).to(dev())
+    w12 = (torch.randn(2816, D, generator=g) * D ** -0.5).to(torch.bfloat16).to(dev())
+    b12 = torch.randn(2816, generator=g).to(dev())
+    wl = (torch.randn(2048, D, generator=g) * D ** -0.5).to(torch.bfloat16).to(dev())
+    q0, k0, v0 = ops.gemm_heads(a, wq, 8, 1024, [ops.PART_Q, ops.PART_K, ops.PART_V], 0.125 * ops.LOG2E)
+    h0 = ops.gemm_swiglu(a, w12, b12)
+    l0 = ops.gemm(a, wl, out_dtype=torch.float32)
+    o0 = ops.attention(q0, k0, v0, 1024, use_exp2=True)
+    for i in range(150):
+        q, k, v = ops.gemm_heads(a, wq, 8, 1024, [ops.PART_Q, ops.PART_K, ops.PART_V], 0.125 * ops.LOG2E)
+        o = ops.attention(q, k, v, 1024, use_exp2=True)
+        h = ops.gemm_swiglu(a, w12, b12)
+        l = ops.gemm(a, wl, out_dtype=torch.float32)
+        assert torch.equal(q, q0) and torch.equal(k, k0) and torch.equal(v, v0), i
+        assert torch.equal(o, o0), i
+        assert torch.equal(h, h0) and torch.equal(l, l0), i
