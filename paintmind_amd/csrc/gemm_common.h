@@ -62,8 +62,11 @@ __device__ __forceinline__ uint4 read_frag(const unsigned char* lds_tile, int ro
 
 // silu(x1) * x2.  fast (bf16 mode): exp2-based exponential and a hardware reciprocal (the result is rounded to
 // bf16 anyway); exact (f32 verify mode): accurate expf and an IEEE divide, like torch's CPU silu.
+__device__ __forceinline__ float silu_mul_fast(float x1, float x2) {
+    return x1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x1 * -1.4426950408889634f)) * x2;
+}
 __device__ __forceinline__ float silu_mul(float x1, float x2, int fast) {
-    if (fast) return x1 * __builtin_amdgcn_rcpf(1.0f + __expf(-x1)) * x2;
+    if (fast) return silu_mul_fast(x1, x2);
     return (x1 / (1.0f + expf(-x1))) * x2;
 }
 
@@ -303,15 +306,15 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
         auto stage = [&](int mi) {
             unsigned char* row = eraw + (mi & 1) * BUFB + l15 * RS;
             *reinterpret_cast<uint2*>(row + g * 8) = make_uint2(
-                pack_bf16x2(silu_mul(acc[mi][0][0] + sb[0].x, acc[mi][1][0] + sb[1].x, p.fast_math),
-                            silu_mul(acc[mi][0][1] + sb[0].y, acc[mi][1][1] + sb[1].y, p.fast_math)),
-                pack_bf16x2(silu_mul(acc[mi][0][2] + sb[0].z, acc[mi][1][2] + sb[1].z, p.fast_math),
-                            silu_mul(acc[mi][0][3] + sb[0].w, acc[mi][1][3] + sb[1].w, p.fast_math)));
+                pack_bf16x2(silu_mul_fast(acc[mi][0][0] + sb[0].x, acc[mi][1][0] + sb[1].x),
+                            silu_mul_fast(acc[mi][0][1] + sb[0].y, acc[mi][1][1] + sb[1].y)),
+                pack_bf16x2(silu_mul_fast(acc[mi][0][2] + sb[0].z, acc[mi][1][2] + sb[1].z),
+                            silu_mul_fast(acc[mi][0][3] + sb[0].w, acc[mi][1][3] + sb[1].w)));
             *reinterpret_cast<uint2*>(row + 32 + g * 8) = make_uint2(
-                pack_bf16x2(silu_mul(acc[mi][2][0] + sb[2].x, acc[mi][3][0] + sb[3].x, p.fast_math),
-                            silu_mul(acc[mi][2][1] + sb[2].y, acc[mi][3][1] + sb[3].y, p.fast_math)),
-                pack_bf16x2(silu_mul(acc[mi][2][2] + sb[2].z, acc[mi][3][2] + sb[3].z, p.fast_math),
-                            silu_mul(acc[mi][2][3] + sb[2].w, acc[mi][3][3] + sb[3].w, p.fast_math)));
+                pack_bf16x2(silu_mul_fast(acc[mi][2][0] + sb[2].x, acc[mi][3][0] + sb[3].x),
+                            silu_mul_fast(acc[mi][2][1] + sb[2].y, acc[mi][3][1] + sb[3].y)),
+                pack_bf16x2(silu_mul_fast(acc[mi][2][2] + sb[2].z, acc[mi][3][2] + sb[3].z),
+                            silu_mul_fast(acc[mi][2][3] + sb[2].w, acc[mi][3][3] + sb[3].w)));
         };
         stage(0);
         const int erow = lane >> 2, q = lane & 3;
