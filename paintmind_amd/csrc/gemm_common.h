@@ -158,21 +158,18 @@ template <int MI>
 __device__ __forceinline__ void ln_apply(const float* scratch, f32x4_t (&acc)[MI][4], int lane, const float (&fa)[MI],
                                          const float (&fb)[MI]) {
     const int g = lane >> 4;
-    float4 cc[4], dd[4];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        cc[ni] = *reinterpret_cast<const float4*>(scratch + 256 + ni * 16 + g * 4);
-        dd[ni] = *reinterpret_cast<const float4*>(scratch + 256 + 64 + ni * 16 + g * 4);
-    }
+    for (int ni = 0; ni < 4; ++ni) {                               // c | d of one 16-column group at a time: 8 live registers, not 32
+        const float4 cc = *reinterpret_cast<const float4*>(scratch + 256 + ni * 16 + g * 4);
+        const float4 dd = *reinterpret_cast<const float4*>(scratch + 256 + 64 + ni * 16 + g * 4);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            acc[mi][ni][0] = fa[mi] * acc[mi][ni][0] + (fb[mi] * cc[ni].x + dd[ni].x);
-            acc[mi][ni][1] = fa[mi] * acc[mi][ni][1] + (fb[mi] * cc[ni].y + dd[ni].y);
-            acc[mi][ni][2] = fa[mi] * acc[mi][ni][2] + (fb[mi] * cc[ni].z + dd[ni].z);
-            acc[mi][ni][3] = fa[mi] * acc[mi][ni][3] + (fb[mi] * cc[ni].w + dd[ni].w);
+        for (int mi = 0; mi < MI; ++mi) {
+            acc[mi][ni][0] = fa[mi] * acc[mi][ni][0] + (fb[mi] * cc.x + dd.x);
+            acc[mi][ni][1] = fa[mi] * acc[mi][ni][1] + (fb[mi] * cc.y + dd.y);
+            acc[mi][ni][2] = fa[mi] * acc[mi][ni][2] + (fb[mi] * cc.z + dd.z);
+            acc[mi][ni][3] = fa[mi] * acc[mi][ni][3] + (fb[mi] * cc.w + dd.w);
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -193,6 +190,7 @@ __device__ __forceinline__ void ln_apply(const float* scratch, f32x4_t (&acc)[MI
 // than the L2 holds, and are next read by a different kernel; measured on the whole bench (same box, tools/ab_same_box.sh):
 // GEMM family 98.7 -> 92.1 ms per step, head-split QKV 103 -> 98.5 us, SwiGLU 203 -> 190 us.
 typedef unsigned nt_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned nt_v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void nt_store16(void* p, uint4 v) {
     __builtin_nontemporal_store(nt_v4u{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_v4u*>(p));
 }
@@ -469,7 +467,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                     nt_store_row(reinterpret_cast<OutT*>(p.out) + (size_t)mm * p.ldo + ncol, v);
                     if constexpr (EMIT && sizeof(OutT) == 4) {
                         // LayerNorm fold: the consumer GEMM reads this row as bf16; its statistics come from the f32 values
-                        store4(p.xb_out + (size_t)mm * p.ldxb + ncol, v[0], v[1], v[2], v[3]);
+                        __builtin_nontemporal_store(nt_v2u{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, reinterpret_cast<nt_v2u*>(p.xb_out + (size_t)mm * p.ldxb + ncol));
                         float s1 = (v[0] + v[1]) + (v[2] + v[3]);
                         float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                         s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);            // the row's 64 columns sit in 16 adjacent lanes
