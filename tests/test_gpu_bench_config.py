@@ -6,7 +6,7 @@ and the north_star model 24L/d768 + 77x768 context at B=32).
     the bf16 logits must stay within a stated distance of the fp32 logits (which are themselves pinned to the
     reference's golden logits at 1e-3 in test_gpu_model.py), and a top-1 flip may only happen where the fp32 top-2
     gap is smaller than twice that distance.
-(b) the exact timed path -- use_graph=True, streams=3 -- must be BIT-identical, ids and every decoded image, to the
+(b) the exact timed path -- use_graph=True, streams=2 (and 3, the earlier default) -- must be BIT-identical, ids and every decoded image, to the
     eager single-stream loop in the same dtype, for two seeds (reference generate.py:183-198 has one code path; ours has
     three and they must agree)."""
 import numpy as np
@@ -85,11 +85,12 @@ def test_timed_path_graph_and_lanes_bit_identical_to_eager(name, B, L, pipe512):
             eager[seed] = (ids.clone(), imgs.clone())
             assert torch.isfinite(imgs).all() and int((ids == pipe.mask_token_id).sum(1).max()) == 1
         assert not torch.equal(eager[1000][0], eager[1001][0])
-        for seed in (1000, 1001, 1000, 1001):                  # eager warm-up of the graph path, capture, two replays
-            ids, imgs = pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=seed, use_graph=True, streams=3)
-            torch.cuda.synchronize()
-            assert torch.equal(ids, eager[seed][0]), (name, seed, float((ids != eager[seed][0]).float().mean()))
-            assert torch.equal(imgs, eager[seed][1]), (name, seed)
+        for lanes in (2, 3):                                   # 2 = what bench.py times (lanes of B/2 + 1 and B/2 - 1 images); 3 = round-2 default
+            for seed in (1000, 1001, 1000, 1001):              # eager warm-up of the graph path, capture, two replays
+                ids, imgs = pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=seed, use_graph=True, streams=lanes)
+                torch.cuda.synchronize()
+                assert torch.equal(ids, eager[seed][0]), (name, lanes, seed, float((ids != eager[seed][0]).float().mean()))
+                assert torch.equal(imgs, eager[seed][1]), (name, lanes, seed)
     finally:
         pipe.set_compute_dtype(torch.float32)
 
