@@ -496,7 +496,17 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
 #undef DSRX
 #undef LGKM_N
 
+// A/B switch while the third-generation bf16 kernel (attention_bf16.hip) is being measured: PMHIP_ATTN_OLD=1
+bool old_bf16_kernel() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PMHIP_ATTN_OLD"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 }  // namespace
+
+int pm_attention_bf16(const void* Q, const void* K, const void* Vt, void* out, int ldo, int B, int heads, int Nq, int Nkv,
+                      int Nkv_pad, int use_exp2, hipStream_t s);
 
 extern "C" int pmhip_attention(int dtype, const void* Q, const void* K, const void* Vt, void* out, int ldo,
                                int B, int heads, int Nq, int Nkv, int Nkv_pad, int use_exp2,
@@ -518,6 +528,8 @@ extern "C" int pmhip_attention(int dtype, const void* Q, const void* K, const vo
         else
             hipLaunchKernelGGL((attention_kernel<float, false, 2>), grid, block, 0, s, (const float*)Q, (const float*)K,
                                (const float*)Vt, (float*)out, ldo, heads, Nq, Nkv, Nkv_pad, nqb);
+    } else if (!old_bf16_kernel()) {
+        PM_TRY(pm_attention_bf16(Q, K, Vt, out, ldo, B, heads, Nq, Nkv, Nkv_pad, use_exp2, s));
     } else {
         const int nqb = ceil_div(Nq, 4 * 4 * 16);
         dim3 grid(nqb * B * heads);

@@ -8,7 +8,7 @@ out="$here/../libpaintmind_hip.so"
 objdir="$here/build"
 mkdir -p "$objdir"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-units="gemm gemm256 gemm2b attention attention_dh rowops vq sample loss engine"
+units="gemm gemm256 gemm2b attention attention_bf16 attention_dh rowops vq sample loss engine"
 hdrsum="$(cat "$here"/*.h "$here/../../include/pmhip.h" | sha256sum | cut -d' ' -f1)"
 pids=(); built=0; reused=0
 for f in $units; do

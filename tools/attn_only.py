@@ -1,5 +1,5 @@
 """attention kernel alone at the bench shape (B=64, H=8, N=1024, dh=64, bf16, exp2): TFLOP/s by hipEvents, plus a
-float64 check of one head.  PMHIP_ATTN32=0 selects the 4-wave 16x16x32 kernel, default the 8-wave 32x32x16 one."""
+float64 check of one head.  PMHIP_ATTN_OLD=1 selects the round-2 kernel (attention.hip) instead of attention_bf16.hip."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,4 +28,4 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f"B={B} H={H} N={N}: {ms * 1e3:.1f} us  {4 * N * N * 64 * B * H / ms / 1e9:.1f} TFLOP/s  (ATTN32={os.environ.get('PMHIP_ATTN32', '1')})")
+print(f"B={B} H={H} N={N}: {ms * 1e3:.1f} us  {4 * N * N * 64 * B * H / ms / 1e9:.1f} TFLOP/s  (ATTN_OLD={os.environ.get('PMHIP_ATTN_OLD', '0')})")
