@@ -273,6 +273,32 @@ def extra_workload(name, dtype_name, steps, device):
     return out
 
 
+def dropin_generate(workload, model, device, steps):
+    """The reference's call, nothing opted into: Pipeline.generate(text, timesteps, temperature, topk, save_interval)
+    (generate.py:183-198) -> list of CPU tensors.  Text tower (synthetic stand-in, or none for the unconditional workload)
+    and the device-to-host copies of the returned images are inside the timed calls."""
+    import torch
+    from paintmind_amd.modules.encoder import NullTextEmbedder
+    cfg_name, B, T, L = WORKLOADS[workload]
+    text = [f"prompt {i}" for i in range(B)]
+    if L is None:
+        model.text_model = NullTextEmbedder()
+    out = {}
+    for si in (1, 2):
+        kw = dict(timesteps=T, temperature=1.0, topk=5, save_interval=si)
+        for i in range(3):                                   # eager pass, capture pass, first replay
+            model.generate(text, seed=1 + i, **kw)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            imgs = model.generate(text, seed=100 + i, **kw)
+        dt = (time.perf_counter() - t0) / steps              # generate() returns with every image on the host
+        out[f"save_interval_{si}"] = {"images_per_s": round(B / dt, 2), "ms_per_call": round(dt * 1e3, 3), "returned_images": len(imgs),
+                                      "d2h_MB_per_call": round(sum(x.numel() for x in imgs) * 4 / 1e6, 1),
+                                      "host_tensors_pinned": bool(imgs[0].is_pinned())}
+    return out
+
+
 def usable_cores():
     """threads this process may actually run on: affinity mask, capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -586,6 +612,16 @@ def main():
         alt = make_step(args.workload, model, device, rank, decode_every_step=False)
         dt = time_steps(alt, device, 2, 1, 3, STREAMS > 1)
         extra["final_decode_only_images_per_s"] = round(B / dt, 2)
+    if rank == 0 and world == 1 and pipeline and not args.final_decode_only and not args.no_extra:
+        log("drop-in Pipeline.generate() with default arguments")
+        try:
+            dg = dropin_generate(args.workload, model, device, max(2, min(args.steps, 5)))
+            # save_interval=1 returns (and copies to the host) the image of EVERY step: the headline's work plus D2H
+            extra["dropin_generate_images_per_s"] = dg["save_interval_1"]["images_per_s"]
+            extra["dropin_generate_vs_headline"] = round(dg["save_interval_1"]["images_per_s"] / value, 4)
+            extra["dropin_generate"] = dg
+        except Exception as e:
+            extra["dropin_generate"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_extra and args.workload == DEFAULT_WORKLOAD and args.dtype == "bf16":
         del step, model
         torch.cuda.empty_cache()

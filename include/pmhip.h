@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PMHIP_ABI_VERSION 4
+#define PMHIP_ABI_VERSION 5
 
 enum { PMHIP_OK = 0, PMHIP_EINVAL = 1, PMHIP_EHIP = 2, PMHIP_ENOMEM = 3, PMHIP_ESTATE = 4 };
 enum { PMHIP_F32 = 0, PMHIP_BF16 = 1 };
@@ -309,14 +309,25 @@ int pmhip_pipeline_sample(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const flo
 /* Pipeline.generate's loop body (generate.py:189-196) for T steps.  temps_host[T], nmask_host[T]
  * are the per-step temperature and num_token_masked the caller derived exactly as the reference
  * does (generate.py:191-193,175); decode_host[T] != 0 selects the steps whose image is produced,
- * written consecutively into imgs_out [n_decoded, B, C, H, W].  The context projection and the
- * cross-attention K/V of the static context are computed once (the reference recomputes them every
- * step, transformer.py:84-85).  use_graph != 0 captures each step into a hipGraph. */
+ * written consecutively into imgs_out [n_decoded, B, C, H, W] (device; may be NULL when imgs_host
+ * is given).  The context projection and the cross-attention K/V of the static context are
+ * computed once (the reference recomputes them every step, transformer.py:84-85).
+ * use_graph != 0: the loop is a chain of hipGraphs, one per segment ending in a decoded step.
+ * imgs_host != NULL replaces the reference's `imgs.append(img.cpu())` (generate.py:195-196): decoded
+ * image d is copied to imgs_host + d * host_stride (floats; the caller's PINNED buffer, so that a
+ * lane can fill its rows of a [n_decoded, B_total, C, H, W] tensor) on copy_stream as soon as it is
+ * complete, under the following steps.  There is no cross-stream wait on the device (a barrier parked
+ * in the copy queue starves concurrent lanes): the CALL paces itself instead -- with imgs_host it
+ * blocks the calling thread between segments (hipEventSynchronize on the image just finished, one
+ * segment always queued ahead) and returns once the last copy is enqueued; concurrent lanes are
+ * driven from one thread each.  The caller synchronises copy_stream before reading the host buffer.
+ * copy_stream NULL: the copies are enqueued on `stream`. */
 int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context,
                             int L, int B, int T, const float* temps_host, const int* nmask_host,
                             const unsigned char* decode_host, int topk, uint64_t seed,
                             uint64_t image_base, float* imgs_out, int use_graph,
-                            pmhip_stream stream);
+                            pmhip_stream stream, float* imgs_host, size_t host_stride,
+                            pmhip_stream copy_stream);
 
 /* Per-kernel timing hook used by bench.py: when enabled, every kernel launch of the named family
  * is bracketed by hipEvents on its own stream and accumulated (count, total ms). */

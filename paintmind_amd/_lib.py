@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpaintmind_hip.so")
 PMHIP_OK = 0
 F32, BF16 = 0, 1
 PART_Q, PART_K, PART_V = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp = C.c_void_p
 i32 = C.c_int
@@ -107,7 +107,7 @@ PROTOTYPES = {
     "pmhip_s2_forward": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "pmhip_pipeline_sample": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, u64, u32, u64, vp, vp, vp, vp]),
     "pmhip_pipeline_generate": (i32, [vp, vp, vp, vp, i32, i32, i32, C.POINTER(f32), C.POINTER(i32),
-                                      C.POINTER(C.c_ubyte), i32, u64, u64, vp, i32, vp]),
+                                      C.POINTER(C.c_ubyte), i32, u64, u64, vp, i32, vp, vp, C.c_size_t, vp]),
     "pmhip_timing_enable": (i32, [i32]),
     "pmhip_timing_reset": (i32, []),
     "pmhip_timing_get": (i32, [C.c_char_p, C.POINTER(i32), C.POINTER(C.c_double)]),

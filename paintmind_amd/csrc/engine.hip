@@ -433,8 +433,13 @@ extern "C" int pmhip_vqgan_decoder_forward(pmhip_vqgan* h, const float* x, int B
 // ------------------------------------------------------------------------------------------------
 struct GraphEntry {
     bool warmed = false;            // one eager pass has sized every workspace buffer
-    hipGraphExec_t exec = nullptr;
-    uint64_t s2_gen = 0, vq_gen = 0;   // workspace generations the graph's baked-in pointers belong to
+    std::vector<hipGraphExec_t> segs;   // one executable graph per segment (a segment ends with a decoded step)
+    uint64_t s2_gen = 0, vq_gen = 0;   // workspace generations the graphs' baked-in pointers belong to
+    void destroy() {
+        for (auto e : segs)
+            if (e) (void)hipGraphExecDestroy(e);
+        segs.clear();
+    }
 };
 
 struct pmhip_s2 {
@@ -446,10 +451,26 @@ struct pmhip_s2 {
     Workspace ws;
     std::map<std::string, GraphEntry> graphs;   // captured decode loops, keyed by shape / schedule structure
     hipStream_t capture_stream = nullptr;       // capture never happens on the caller's stream (it may be the NULL stream)
+    // per-call scalars travel through PINNED host slots (a pageable source makes hipMemcpyAsync stage synchronously);
+    // a slot is reused only after the copy that read it has completed
+    static constexpr int kParamSlots = 4;
+    PmGenParams* params_host = nullptr;
+    hipEvent_t params_done[kParamSlots] = {};
+    int params_next = 0;
+    // device image d complete -> copy stream (one event per image of a call: an event is never re-recorded while a wait on
+    // its previous record may still be queued); last D2H complete -> next call
+    std::vector<hipEvent_t> img_ready;
+    hipEvent_t host_copied = nullptr;
+    bool host_copy_pending = false;
     ~pmhip_s2() {
-        for (auto& kv : graphs)
-            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        for (auto& kv : graphs) kv.second.destroy();
         if (capture_stream) (void)hipStreamDestroy(capture_stream);
+        if (params_host) (void)hipHostFree(params_host);
+        for (auto e : params_done)
+            if (e) (void)hipEventDestroy(e);
+        for (auto e : img_ready)
+            if (e) (void)hipEventDestroy(e);
+        if (host_copied) (void)hipEventDestroy(host_copied);
     }
 };
 
@@ -588,91 +609,176 @@ extern "C" int pmhip_pipeline_sample(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids
 extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context, int L, int B,
                                        int T, const float* temps_host, const int* nmask_host,
                                        const unsigned char* decode_host, int topk, uint64_t seed, uint64_t image_base,
-                                       float* imgs_out, int use_graph, pmhip_stream stream) {
+                                       float* imgs_out, int use_graph, pmhip_stream stream, float* imgs_host,
+                                       size_t host_stride, pmhip_stream copy_stream) {
     PM_REQUIRE(s2 && ids && B > 0 && T > 0 && temps_host && nmask_host, "pipeline_generate: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    hipStream_t cs = copy_stream ? (hipStream_t)copy_stream : s;
     PM_TRY(s2_prepare_context(s2, context, L, B, s));         // context projection + cross K/V: once per loop, eager
     size_t img_elems = 0;
     if (vq) img_elems = (size_t)B * vq->cfg.channels * vq->cfg.image_size * vq->cfg.image_size;
     int n_dec = 0;
     for (int t = 0; t < T; ++t) n_dec += (decode_host && decode_host[t]) ? 1 : 0;
-    PM_REQUIRE(n_dec == 0 || (vq && imgs_out), "pipeline_generate: decode requested without vqgan/imgs_out");
+    PM_REQUIRE(n_dec == 0 || (vq && (imgs_out || imgs_host)), "pipeline_generate: decode requested without vqgan / an image destination");
+    PM_REQUIRE(!imgs_host || host_stride >= img_elems, "pipeline_generate: host_stride smaller than one image batch");
+    const bool graph = use_graph && !g_pm_timing_on && T <= PM_MAX_STEPS;
 
-    if (!use_graph || g_pm_timing_on || T > PM_MAX_STEPS) {
-        int d = 0;
-        for (int t = 0; t < T; ++t) {
-            float* img = (decode_host && decode_host[t]) ? imgs_out + (size_t)(d++) * img_elems : nullptr;
-            PM_TRY(sample_step(s2, vq, ids, B, topk, temps_host[t], nmask_host[t], nullptr, seed, (uint32_t)t, image_base, img,
-                               nullptr, nullptr, s));
+    if (imgs_host) {
+        const unsigned evflags = hipEventDisableTiming;
+        if (!s2->host_copied) PM_HIP(hipEventCreateWithFlags(&s2->host_copied, evflags));
+        while ((int)s2->img_ready.size() < n_dec) {
+            hipEvent_t e;
+            PM_HIP(hipEventCreateWithFlags(&e, evflags));
+            s2->img_ready.push_back(e);
+        }
+    }
+    // images are produced into a handle-owned buffer when a graph bakes the pointer in or when the caller only wants the
+    // host copy; that buffer must not be overwritten while the previous call's last device-to-host copy still reads it
+    float* gimgs = nullptr;
+    if (n_dec && (graph || !imgs_out)) {
+        WS(s2->ws, "gen.imgs", (size_t)n_dec * img_elems * 4 + 16, gimgs);
+        if (s2->host_copy_pending) { PM_HIP(hipStreamWaitEvent(s, s2->host_copied, 0)); s2->host_copy_pending = false; }
+    }
+    // Image d is complete on `s` after the step that decodes it.  Device destination: a copy on `s`.  Host destination: the
+    // copy must run on the copy stream UNDER the following steps, but it is not made to wait there by a cross-stream event:
+    // a barrier packet parked at the head of the copy queue until a whole segment has run starves the other lane's queue
+    // on this part (measured: two lanes with such waits run one after the other, 164 vs 138 ms per call).  Instead the HOST
+    // paces the loop, like the reference's blocking `img.cpu()` per saved step (generate.py:195-196): once the next
+    // segment is queued it waits for image d's event and enqueues a copy that can start at once.  The caller runs
+    // concurrent lanes from one thread each (the ctypes call drops the GIL).
+    int pending = -1;                                         // decoded image whose host copy has not been enqueued yet
+    const float* pending_src = nullptr;
+    auto flush_pending = [&]() -> int {
+        if (pending < 0) return PMHIP_OK;
+        if (cs != s) PM_HIP(hipEventSynchronize(s2->img_ready[pending]));
+        PM_HIP(hipMemcpyAsync(imgs_host + (size_t)pending * host_stride, pending_src, img_elems * 4, hipMemcpyDeviceToHost, cs));
+        if (pending == n_dec - 1 && gimgs) {
+            PM_HIP(hipEventRecord(s2->host_copied, cs));
+            s2->host_copy_pending = cs != s;
+        }
+        pending = -1;
+        return PMHIP_OK;
+    };
+    auto deliver = [&](int d, const float* src) -> int {
+        if (imgs_out && src != imgs_out + (size_t)d * img_elems)
+            PM_HIP(hipMemcpyAsync(imgs_out + (size_t)d * img_elems, src, img_elems * 4, hipMemcpyDeviceToDevice, s));
+        if (imgs_host) {
+            if (cs != s) PM_HIP(hipEventRecord(s2->img_ready[d], s));
+            pending = d;
+            pending_src = src;
         }
         return PMHIP_OK;
+    };
+
+    if (!graph) {
+        int d = 0;
+        for (int t = 0; t < T; ++t) {
+            const bool dec = decode_host && decode_host[t];
+            float* img = !dec ? nullptr : (gimgs ? gimgs : imgs_out) + (size_t)d * img_elems;
+            PM_TRY(sample_step(s2, vq, ids, B, topk, temps_host[t], nmask_host[t], nullptr, seed, (uint32_t)t, image_base, img,
+                               nullptr, nullptr, s));
+            PM_TRY(flush_pending());                           // the previous image, now that one more step is queued behind it
+            if (dec) PM_TRY(deliver(d++, img));
+        }
+        return flush_pending();
     }
 
-    // ---- hipGraph path.  The whole T-step loop is ONE graph whose kernels read the per-call scalars
-    // (temperatures, mask counts, seed, row base) from a device parameter block and whose ids / image pointers are
-    // handle-owned buffers, so the same executable graph serves every call with this structure.
+    // ---- hipGraph path.  The T-step loop is a chain of graphs, one per SEGMENT (the steps up to and including a decoded
+    // one), whose kernels read the per-call scalars (temperatures, mask counts, seed, row base) from a device parameter
+    // block and whose ids / image pointers are handle-owned buffers, so the same executable graphs serve every call with
+    // this structure; between two segments the finished image starts its way to the host.
     const size_t ids_bytes = (size_t)B * s2->cfg.tokens * 8;
-    int64_t* gids; float* gimgs; PmGenParams* gparams;
+    int64_t* gids; PmGenParams* gparams;
     WS(s2->ws, "gen.ids", ids_bytes, gids);
-    WS(s2->ws, "gen.imgs", (size_t)(n_dec ? n_dec : 1) * img_elems * 4 + 16, gimgs);
     WS(s2->ws, "gen.params", sizeof(PmGenParams), gparams);
-    PmGenParams hp{};
+    if (!s2->params_host) {
+        PM_HIP(hipHostMalloc((void**)&s2->params_host, sizeof(PmGenParams) * pmhip_s2::kParamSlots, hipHostMallocDefault));
+        for (auto& e : s2->params_done) PM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int slot = s2->params_next;
+    s2->params_next = (slot + 1) % pmhip_s2::kParamSlots;
+    PM_HIP(hipEventSynchronize(s2->params_done[slot]));       // the copy that last read this slot (no-op when never recorded)
+    PmGenParams& hp = s2->params_host[slot];
     hp.seed = seed;
     hp.row_base = image_base * (uint64_t)s2->cfg.tokens;
     for (int t = 0; t < T; ++t) { hp.temps[t] = temps_host[t]; hp.nmask[t] = nmask_host[t]; }
-    PM_HIP(hipMemcpyAsync(gparams, &hp, sizeof hp, hipMemcpyHostToDevice, s));       // pageable source: staged synchronously
+    PM_HIP(hipMemcpyAsync(gparams, &hp, sizeof hp, hipMemcpyHostToDevice, s));
+    PM_HIP(hipEventRecord(s2->params_done[slot], s));
     PM_HIP(hipMemcpyAsync(gids, ids, ids_bytes, hipMemcpyDeviceToDevice, s));
 
     std::string key = "B" + std::to_string(B) + "T" + std::to_string(T) + "k" + std::to_string(topk) + "L" +
-                      std::to_string(context ? L : 0) + "v" + std::to_string(vq ? vq->uid : 0) + "d";
+                      std::to_string(context ? L : 0) + "v" + std::to_string(vq ? vq->uid : 0) + "f" +
+                      std::to_string(ln_fold_enabled() ? 1 : 0) + "d";
     for (int t = 0; t < T; ++t) key += (decode_host && decode_host[t]) ? '1' : '0';
     GraphEntry& ge = s2->graphs[key];
 
-    auto run_steps = [&](hipStream_t on) -> int {
-        int d = 0;
-        for (int t = 0; t < T; ++t) {
+    std::vector<std::pair<int, int>> segs;                    // [t0, t1): t1 - 1 is a decoded step, or the end of the loop
+    for (int t = 0, t0 = 0; t < T; ++t)
+        if ((decode_host && decode_host[t]) || t == T - 1) { segs.emplace_back(t0, t + 1); t0 = t + 1; }
+
+    // d0 = number of images decoded before step t0
+    auto run_steps = [&](hipStream_t on, int t0, int t1, int d0) -> int {
+        int d = d0;
+        for (int t = t0; t < t1; ++t) {
             float* img = (decode_host && decode_host[t]) ? gimgs + (size_t)(d++) * img_elems : nullptr;
             PM_TRY(sample_step(s2, vq, gids, B, topk, 0.f, 0, nullptr, 0, (uint32_t)t, 0, img, nullptr, nullptr, on, gparams));
         }
         return PMHIP_OK;
     };
+    auto seg_decodes = [&](int i) { return decode_host && decode_host[segs[i].second - 1]; };
 
     if (!ge.warmed) {
-        PM_TRY(run_steps(s));                                  // eager once: sizes every workspace buffer
+        int d = 0;
+        for (size_t i = 0; i < segs.size(); ++i) {             // eager once: sizes every workspace buffer
+            PM_TRY(run_steps(s, segs[i].first, segs[i].second, d));
+            PM_TRY(flush_pending());
+            if (seg_decodes((int)i)) { PM_TRY(deliver(d, gimgs + (size_t)d * img_elems)); ++d; }
+        }
         ge.warmed = true;
     } else {
         // a workspace buffer of either handle was reallocated since the capture (a later call with a larger batch, a
-        // longer context, a direct encode/decode on the shared vqgan handle ...): the graph's pointers are stale
-        if (ge.exec && (ge.s2_gen != s2->ws.gen || (vq && ge.vq_gen != vq->ws.gen))) {
+        // longer context, a direct encode/decode on the shared vqgan handle ...): the graphs' pointers are stale
+        if (!ge.segs.empty() && (ge.s2_gen != s2->ws.gen || (vq && ge.vq_gen != vq->ws.gen))) {
             PM_HIP(hipStreamSynchronize(s));                  // an earlier replay may still be running
-            (void)hipGraphExecDestroy(ge.exec);
-            ge.exec = nullptr;
+            ge.destroy();
         }
-        if (!ge.exec) {
+        if (ge.segs.empty()) {
             if (!s2->capture_stream) PM_HIP(hipStreamCreateWithFlags(&s2->capture_stream, hipStreamNonBlocking));
             hipStream_t cap = s2->capture_stream;
-            hipGraph_t graph = nullptr;
-            s2->ws.frozen = true;
-            if (vq) vq->ws.frozen = true;
-            hipError_t rc = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
-            int step_rc = PMHIP_OK;
-            if (rc == hipSuccess) {
-                step_rc = run_steps(cap);                      // records only: nothing executes during capture
-                rc = hipStreamEndCapture(cap, &graph);
+            int d = 0;
+            for (size_t i = 0; i < segs.size(); ++i) {
+                hipGraph_t g = nullptr;
+                hipGraphExec_t exec = nullptr;
+                s2->ws.frozen = true;
+                if (vq) vq->ws.frozen = true;
+                hipError_t rc = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+                int step_rc = PMHIP_OK;
+                if (rc == hipSuccess) {
+                    step_rc = run_steps(cap, segs[i].first, segs[i].second, d);   // records only: nothing executes during capture
+                    rc = hipStreamEndCapture(cap, &g);
+                }
+                s2->ws.frozen = false;
+                if (vq) vq->ws.frozen = false;
+                if (step_rc == PMHIP_OK && rc == hipSuccess) rc = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+                if (g) (void)hipGraphDestroy(g);
+                if (step_rc != PMHIP_OK || rc != hipSuccess) {
+                    ge.destroy();
+                    if (step_rc != PMHIP_OK) return step_rc;
+                    PM_HIP(rc);
+                }
+                ge.segs.push_back(exec);
+                if (seg_decodes((int)i)) ++d;
             }
-            s2->ws.frozen = false;
-            if (vq) vq->ws.frozen = false;
-            if (step_rc != PMHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return step_rc; }
-            PM_HIP(rc);
-            rc = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            PM_HIP(rc);
             ge.s2_gen = s2->ws.gen;
             ge.vq_gen = vq ? vq->ws.gen : 0;
         }
-        PM_HIP(hipGraphLaunch(ge.exec, s));
+        int d = 0;
+        for (size_t i = 0; i < segs.size(); ++i) {
+            PM_HIP(hipGraphLaunch(ge.segs[i], s));
+            PM_TRY(flush_pending());
+            if (seg_decodes((int)i)) { PM_TRY(deliver(d, gimgs + (size_t)d * img_elems)); ++d; }
+        }
     }
     PM_HIP(hipMemcpyAsync(ids, gids, ids_bytes, hipMemcpyDeviceToDevice, s));
-    if (n_dec) PM_HIP(hipMemcpyAsync(imgs_out, gimgs, (size_t)n_dec * img_elems * 4, hipMemcpyDeviceToDevice, s));
-    return PMHIP_OK;
+    return flush_pending();
 }

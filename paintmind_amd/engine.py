@@ -288,16 +288,30 @@ class S2Engine:
                 _p(pred), _p(score), stream_ptr(self.device)), "pmhip_pipeline_sample")
         return ids, img, pred, score
 
-    def generate(self, vq_engine, ids, context, temps, nmask, decode_flags, topk, seed=0, image_base=0, use_graph=False):
-        """T MaskGIT steps in one native call; returns imgs [n_decoded, B, C, H, W] (device)."""
+    def generate(self, vq_engine, ids, context, temps, nmask, decode_flags, topk, seed=0, image_base=0, use_graph=False,
+                 host=None, want_device_imgs=True):
+        """T MaskGIT steps in one native call; returns imgs [n_decoded, B, C, H, W] (device) or None.
+
+        host = (pinned float32 tensor [n_decoded, B_total, C, H, W], first row of this batch, copy stream): every decoded
+        image is copied into its rows on the copy stream as soon as it is complete (the reference's `img.cpu()`,
+        generate.py:195-196); the caller synchronises that stream."""
         B = ids.shape[0]
         T = len(temps)
         context, L = self._ctx(context)
         n_dec = int(sum(1 for f in decode_flags if f))
         imgs = None
-        if n_dec:
+        if n_dec and (want_device_imgs or host is None):
             imgs = torch.empty(n_dec, B, vq_engine.channels, vq_engine.image_size, vq_engine.image_size, device=self.device,
                                dtype=torch.float32)
+        host_ptr, host_stride, copy_stream = C.c_void_p(0), 0, C.c_void_p(0)
+        if host is not None and n_dec:
+            buf, row0, cstream = host
+            if not (buf.is_pinned() and buf.dtype == torch.float32 and buf.is_contiguous() and buf.shape[0] == n_dec):
+                raise ValueError("host image buffer must be a pinned contiguous float32 tensor [n_decoded, B_total, C, H, W]")
+            per_img = buf[0, 0].numel()
+            host_ptr = C.c_void_p(buf.data_ptr() + row0 * per_img * 4)
+            host_stride = buf.shape[1] * per_img
+            copy_stream = C.c_void_p(cstream.cuda_stream)
         temps_c = (C.c_float * T)(*[float(t) for t in temps])
         nmask_c = (C.c_int * T)(*[int(n) for n in nmask])
         dec_c = (C.c_ubyte * T)(*[1 if f else 0 for f in decode_flags])
@@ -305,5 +319,5 @@ class S2Engine:
             check(self.lib.pmhip_pipeline_generate(
                 self.handle, vq_engine.handle if vq_engine is not None else C.c_void_p(0), _p(ids), _p(context), L, B, T,
                 temps_c, nmask_c, dec_c, int(topk), int(seed), int(image_base), _p(imgs), int(use_graph),
-                stream_ptr(self.device)), "pmhip_pipeline_generate")
+                stream_ptr(self.device), host_ptr, host_stride, copy_stream), "pmhip_pipeline_generate")
         return ids, imgs

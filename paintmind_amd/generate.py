@@ -6,7 +6,7 @@ Kept 1:1 with the reference: constructor wiring and parameter names, ``to_latent
 return structures and the quirks listed in SURVEY.md section 8(a) (image decoded from the predictions at
 ALL positions, confidence from the unfiltered softmax, >= 1 token re-masked on the last step,
 ``generate`` returning only the steps with ``step % save_interval == 0`` as CPU tensors).
-Training-only members (forward / loss / random_masking, generate.py:78-146) are out of scope.
+The masked-token objective (forward / loss / random_masking, generate.py:78-146) is built forward-only: no backward.
 """
 import math
 
@@ -39,6 +39,46 @@ def num_token_masked(mask_ratio, num_tokens):
     r = mask_ratio * num_tokens
     r = r.item() if hasattr(r, "item") else r
     return max(int(r), 1)
+
+
+class _PinnedPool:
+    """Pinned host buffers for the images generate() returns.  Page-locking a fresh 400 MB allocation costs ~35 ms (more
+    than the copies themselves), so buffers are kept and handed out again -- but only once nothing the caller received
+    still aliases them: every returned tensor (and any view / numpy alias of it) holds a reference to the buffer's
+    storage, so a use count of 2 (the pool's tensor + the probe) means the earlier results are gone.  Results a caller
+    keeps stay valid for ever; their buffer simply leaves the pool."""
+    MAX_KEPT = 4
+
+    def __init__(self):
+        self.bufs = []
+
+    @staticmethod
+    def _free(t):
+        return torch._C._storage_Use_Count(t.untyped_storage()._cdata) <= 2
+
+    def get(self, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        for t in self.bufs:
+            if t.numel() == n and self._free(t):
+                return t.view(shape)
+        t = torch.empty(n, dtype=torch.float32, pin_memory=True)
+        self.bufs = [b for b in self.bufs if not (self._free(b) and b.numel() != n)][-(self.MAX_KEPT - 1):] + [t]
+        return t.view(shape)
+
+
+_pinned_pool = _PinnedPool()
+_lane_threads = None
+
+
+def _lane_thread_pool(n):
+    """process-wide worker threads that drive concurrent micro-batch lanes (kept out of the Module: it stays copyable)"""
+    global _lane_threads
+    if _lane_threads is None or _lane_threads._max_workers < n:
+        from concurrent.futures import ThreadPoolExecutor
+        _lane_threads = ThreadPoolExecutor(max_workers=max(n, 2), thread_name_prefix="pm-lane")
+    return _lane_threads
 
 
 T5_VERSION = {'t5-l': 'google/flan-t5-large', 't5-xl': 'google/flan-t5-xl', 't5-xxl': 'google/flan-t5-xxl'}
@@ -110,6 +150,7 @@ class Pipeline(nn.Module):
         """drop every packed weight copy / captured graph of this pipeline and its VQGAN"""
         self._engine = None
         self._lane_cache = None
+        self._copy_streams = None
         self.vqgan.invalidate_engines()
 
     def from_pretrained(self, path):
@@ -204,7 +245,7 @@ class Pipeline(nn.Module):
         return lanes[:k]
 
     def generate_ids(self, context, B, timesteps, temperature, topk, decode_flags, seed, image_base=0, use_graph=False, streams=1,
-                     join=True, wait_current=True):
+                     join=True, wait_current=True, host=None):
         """The decode loop on device tensors: returns (ids [B,N], imgs [n_decoded,B,C,H,W] or None).
 
         streams > 1 (or a tuple of micro-batch sizes): the batch is cut into contiguous micro-batches that run CONCURRENTLY on separate HIP
@@ -213,7 +254,10 @@ class Pipeline(nn.Module):
         identical to streams=1.
         join=False returns the per-lane results [(ids, imgs, stream), ...] without making the current stream wait (the
         caller joins); wait_current=False does not make the lanes wait for work already queued on the current stream
-        (only valid when `context` is None or was produced before the lanes last synchronised with it)."""
+        (only valid when `context` is None or was produced before the lanes last synchronised with it).
+        host = (pinned [n_decoded, B, C, H, W] float32 tensor, [copy stream per lane]): the decoded images go straight to
+        the host buffer (every lane fills its rows, each image as soon as it is complete, on its own copy stream); no
+        device image tensor is returned."""
         eng = self.engine()
         temps, nmask = self._schedule(timesteps, temperature)
         if isinstance(streams, (list, tuple)):           # explicit micro-batch sizes, e.g. (32, 16, 16)
@@ -232,23 +276,35 @@ class Pipeline(nn.Module):
         if streams == 1:
             ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
             return eng.generate(self.vqgan.engine(), ids, context, temps, nmask, decode_flags, topk, seed=seed,
-                                image_base=image_base, use_graph=use_graph)
+                                image_base=image_base, use_graph=use_graph,
+                                host=None if host is None else (host[0], 0, host[1][0]), want_device_imgs=host is None)
         from .dist import shard_range
         cur = torch.cuda.current_stream(eng.device)
         if wait_current:
             ready = torch.cuda.Event()
             ready.record(cur)
-        parts = []
-        for i, (e, v, st) in enumerate(self._lanes(streams)):
+
+        def run_lane(i, e, v, st):
             lo, hi = bounds[i] if bounds is not None else shard_range(B, i, streams)
             if wait_current:
                 st.wait_event(ready)
-            with torch.cuda.stream(st):
+            with torch.cuda.device(eng.device), torch.cuda.stream(st):
                 ids = torch.full((hi - lo, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
                 c = None if context is None else context[lo:hi].contiguous()
                 ids, imgs = e.generate(v, ids, c, temps, nmask, decode_flags, topk, seed=seed, image_base=image_base + lo,
-                                       use_graph=use_graph)
-                parts.append((ids, imgs, st))
+                                       use_graph=use_graph, host=None if host is None else (host[0], lo, host[1][i]),
+                                       want_device_imgs=host is None)
+            return ids, imgs, st
+
+        lanes = self._lanes(streams)
+        if host is None:
+            parts = [run_lane(i, e, v, st) for i, (e, v, st) in enumerate(lanes)]
+        else:
+            # with a host destination the native call paces its lane from the host (it blocks between segments, see
+            # pmhip_pipeline_generate), so every lane is driven by its own thread; ctypes drops the GIL during the call
+            pool = _lane_thread_pool(streams)
+            futs = [pool.submit(run_lane, i, e, v, st) for i, (e, v, st) in enumerate(lanes)]
+            parts = [f.result() for f in futs]               # re-raises a lane's exception here
         if not join:
             return parts
         return self.join_lanes(parts)
@@ -266,21 +322,46 @@ class Pipeline(nn.Module):
         return ids, imgs
 
     def generate(self, text, timesteps=18, temperature=1.0, topk=5, save_interval=2, seed=None, image_base=0,
-                 return_ids=False, keep_on_device=False, use_graph=False, streams=1):
-        """Full decode loop (generate.py:183-198): list of (B,3,H,W) CPU tensors for steps % save_interval == 0."""
+                 return_ids=False, keep_on_device=False, use_graph=None, streams=None):
+        """Full decode loop (generate.py:183-198): list of (B,3,H,W) CPU tensors for steps % save_interval == 0.
+
+        The call is the fast path by default: the loop replays captured hipGraphs (first call eager, second call captures),
+        in bf16 mode the batch runs as two concurrent micro-batch lanes, and every saved image starts its copy into a
+        pinned host buffer on a copy stream as soon as its step is done (the reference's blocking `img.cpu()` per saved
+        step, generate.py:195-196), so only the last image's copy is exposed.  use_graph / streams override the defaults;
+        results are bit-identical for every setting (tests/test_gpu_model.py)."""
         B = len(text)
         context = self.text_model(text)
         eng = self.engine()
         if seed is None:
             seed = _draw_seed()
+        if use_graph is None:
+            use_graph = True
+        if streams is None:
+            streams = 2 if (self.compute_dtype == torch.bfloat16 and B >= 8) else 1
         flags = [step % save_interval == 0 for step in range(timesteps)]
-        # use_graph: the T-step loop is captured into one hipGraph (first call eager, second call captures, later
-        # calls replay); per-call scalars (seed, schedule values) are read from device memory, so one graph serves all
         if context is not None:
             context = context.to(eng.device)
-        ids, imgs = self.generate_ids(context, B, timesteps, temperature, topk, flags, seed, image_base=image_base,
-                                      use_graph=use_graph, streams=streams)
-        out = [] if imgs is None else [im if keep_on_device else im.cpu() for im in imgs]
+        n_dec = sum(flags)
+        if keep_on_device or n_dec == 0:
+            ids, imgs = self.generate_ids(context, B, timesteps, temperature, topk, flags, seed, image_base=image_base,
+                                          use_graph=use_graph, streams=streams)
+            out = [] if imgs is None else list(imgs)
+            return (out, ids) if return_ids else out
+        vq = self.vqgan.engine()
+        host = _pinned_pool.get((n_dec, B, vq.channels, vq.image_size, vq.image_size))
+
+        n_lanes = len(streams) if isinstance(streams, (list, tuple)) else max(1, min(int(streams), B))
+        cs = getattr(self, "_copy_streams", None)
+        if cs is None or cs[0].device != eng.device:
+            cs = self._copy_streams = []
+        while len(cs) < n_lanes:
+            cs.append(torch.cuda.Stream(device=eng.device))
+        ids, _ = self.generate_ids(context, B, timesteps, temperature, topk, flags, seed, image_base=image_base,
+                                   use_graph=use_graph, streams=streams, host=(host, cs))
+        for c in cs[:n_lanes]:
+            c.synchronize()                                  # every image has landed in the host buffer
+        out = list(host)                                     # views of one pinned buffer; it is reused once all of them are gone
         return (out, ids) if return_ids else out
 
     def _region_loop(self, img, coord, text, timesteps, topk, temperature, keep_inside, seed=None, return_ids=False):

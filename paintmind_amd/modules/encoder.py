@@ -113,6 +113,14 @@ class CLIPTextEmbedder(nn.Module):
         return self(text)
 
 
+class NullTextEmbedder(nn.Module):
+    """Unconditional generation through the drop-in API: the context is None, so attn2 runs as a second self-attention
+    (reference modules/attention.py:47).  BASELINE.json configs[2] is this path."""
+
+    def forward(self, text):
+        return None
+
+
 class SyntheticTextEmbedder(nn.Module):
     """Deterministic stand-in used by the benches and tests: N(0,1) features keyed by (seed, prompt index).
 

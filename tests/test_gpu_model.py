@@ -154,7 +154,8 @@ def test_generate_hipgraph_replay_is_bit_identical(tiny_pipe):
     """eager pass, capture pass and replays of the graph-captured decode loop give the eager results for every seed"""
     pipe, p, d = tiny_pipe
     texts = ["a", "b", "c"]
-    eager = {sd: pipe.generate(texts, timesteps=6, topk=4, save_interval=1, seed=sd, return_ids=True) for sd in (1, 2, 3, 4)}
+    eager = {sd: pipe.generate(texts, timesteps=6, topk=4, save_interval=1, seed=sd, return_ids=True, use_graph=False, streams=1)
+             for sd in (1, 2, 3, 4)}
     for sd in (1, 2, 3, 4, 2):          # 1: eager warm-up inside the graph path, 2: capture + launch, then replays
         imgs, ids = pipe.generate(texts, timesteps=6, topk=4, save_interval=1, seed=sd, return_ids=True, use_graph=True)
         assert torch.equal(ids, eager[sd][1]), sd
@@ -162,8 +163,38 @@ def test_generate_hipgraph_replay_is_bit_identical(tiny_pipe):
     # a different schedule structure gets its own graph
     a = pipe.generate(texts, timesteps=4, topk=4, save_interval=2, seed=9, use_graph=True)
     b = pipe.generate(texts, timesteps=4, topk=4, save_interval=2, seed=9, use_graph=True)
-    c = pipe.generate(texts, timesteps=4, topk=4, save_interval=2, seed=9)
+    c = pipe.generate(texts, timesteps=4, topk=4, save_interval=2, seed=9, use_graph=False, streams=1)
     assert all(torch.equal(x, y) and torch.equal(x, z) for x, y, z in zip(a, b, c))
+
+
+def test_generate_default_call_is_the_fast_path_and_matches_the_eager_loop(tiny_pipe):
+    """Pipeline.generate() with no opt-ins (reference generate.py:183-198): segment graphs, lanes in bf16 mode, saved images
+    copied to a pinned host buffer on a copy stream under the following steps.  The returned list must be bit-identical
+    to the eager single-stream loop with blocking copies, for both save intervals, in both precision modes."""
+    pipe, p, d = tiny_pipe
+    texts = [f"t{i}" for i in range(9)]
+    try:
+        for dtype in (torch.float32, torch.bfloat16):
+            pipe.set_compute_dtype(dtype)
+            for si in (1, 2, 3):
+                kw = dict(timesteps=7, topk=4, save_interval=si, seed=31 + si, return_ids=True)
+                ref_dev, ref_ids = pipe.generate(texts, use_graph=False, streams=1, keep_on_device=True, **kw)
+                ref = [im.cpu() for im in ref_dev]
+                for rep in range(3):                              # eager pass, capture pass, replay
+                    imgs, ids = pipe.generate(texts, **kw)
+                    assert len(imgs) == len(ref) == len(range(0, 7, si))
+                    assert torch.equal(ids, ref_ids), (dtype, si, rep)
+                    for a, b in zip(imgs, ref):
+                        assert a.device.type == "cpu" and a.dtype == torch.float32 and a.shape == b.shape
+                        assert torch.equal(a, b), (dtype, si, rep)
+        # earlier results stay valid after later calls (every call owns its host buffer)
+        pipe.set_compute_dtype(torch.float32)
+        first = pipe.generate(texts, timesteps=4, topk=3, seed=5)
+        keep = [x.clone() for x in first]
+        pipe.generate(texts, timesteps=4, topk=3, seed=6)
+        assert all(torch.equal(a, b) for a, b in zip(first, keep))
+    finally:
+        pipe.set_compute_dtype(torch.float32)
 
 
 def test_engine_cache_per_dtype_and_invalidate(tiny_vq):
@@ -208,8 +239,8 @@ def test_hipgraph_survives_workspace_growth(tiny_pipe):
     pipe, p, d = tiny_pipe
     small, big = ["a", "b", "c"], ["a", "b", "c", "d", "e", "f"]
     kw = dict(timesteps=5, topk=4, save_interval=1, return_ids=True)
-    eager_small = pipe.generate(small, seed=21, **kw)
-    eager_big = pipe.generate(big, seed=22, **kw)
+    eager_small = pipe.generate(small, seed=21, use_graph=False, streams=1, **kw)
+    eager_big = pipe.generate(big, seed=22, use_graph=False, streams=1, **kw)
     # a fresh engine pair so that the growth really happens after the capture
     pipe.invalidate_engines()
     for _ in range(3):                                        # eager warm-up, capture, replay
@@ -230,7 +261,7 @@ def test_hipgraph_survives_workspace_growth(tiny_pipe):
 def test_generate_concurrent_micro_batches_match_single_stream(tiny_pipe):
     pipe, p, d = tiny_pipe
     texts = ["a", "b", "c", "d", "e"]
-    one = pipe.generate(texts, timesteps=5, topk=3, save_interval=1, seed=11, return_ids=True)
+    one = pipe.generate(texts, timesteps=5, topk=3, save_interval=1, seed=11, return_ids=True, use_graph=False, streams=1)
     for k in (2, 3, 5):
         for graph in (False, True, True):
             many = pipe.generate(texts, timesteps=5, topk=3, save_interval=1, seed=11, return_ids=True, streams=k, use_graph=graph)
