@@ -26,7 +26,12 @@ rc=0
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || rc=1; }; done
 [ $rc -eq 0 ] || { echo "build failed" >&2; exit 1; }
 objs=""; for f in $units; do objs="$objs $objdir/$f.o"; done
-if [ $built -gt 0 ] || [ ! -f "$out" ]; then
+# the link has its own stamp (hash of every object stamp), written only after a successful link: an interrupted or failed
+# link is redone by the next run even though every object is up to date
+linkwant="$(for f in $units; do cat "$objdir/$f.sha"; done | sha256sum | cut -d' ' -f1)"
+if [ ! -f "$out" ] || [ ! -f "$objdir/link.sha" ] || [ "$(cat "$objdir/link.sha")" != "$linkwant" ]; then
+  rm -f "$objdir/link.sha"
   hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" $objs
+  echo "$linkwant" > "$objdir/link.sha"
 fi
 echo "built $out (compiled $built, reused $reused objects)"

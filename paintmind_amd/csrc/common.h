@@ -170,10 +170,6 @@ __device__ __forceinline__ unsigned other32(unsigned v, int lane) {
     auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false);       // a[0] = {lo,lo}, a[1] = {hi,hi}
     return (lane & 32) ? a[0] : a[1];
 }
-__device__ __forceinline__ float swap16(float v) {   // value of lane ^ 16
-    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float((threadIdx.x & 16) ? a[1] : a[0]);
-}
 #ifdef PM_WAVE_REDUCE_BPERMUTE
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

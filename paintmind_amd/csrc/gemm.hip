@@ -215,8 +215,11 @@ int gemm_impl(int dtype, const void* A, int lda, const void* W, int ldw, const f
         PM_TRY(pm_ln_finalize(p.ln_stats, p.ln_nc, p.M, p.ln_eps, ln->coef, stream));
         return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
     }
-    if (use2b(p, dtype, EPI_STD, out_dtype)) return pm_gemm2b_launch(p, EPI_STD, out_dtype, s);
-    if (use256(p, dtype, EPI_STD, out_dtype)) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
+    // the large-tile kernels emit the bf16 copy + row statistics only from their residual epilogue; without a residual the
+    // 128x128 kernel serves the request (it handles every combination)
+    const bool big_ok = !(p.xb_out && !p.residual);
+    if (big_ok && use2b(p, dtype, EPI_STD, out_dtype)) return pm_gemm2b_launch(p, EPI_STD, out_dtype, s);
+    if (big_ok && use256(p, dtype, EPI_STD, out_dtype)) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_STD, float>(p, s);
     if (out_dtype == PMHIP_F32) return launch<bf16_t, EPI_STD, float>(p, s);
     return launch<bf16_t, EPI_STD, bf16_t>(p, s);

@@ -14,7 +14,10 @@
 // the order it will be needed: PA0 (A rows for phase 1), PW0, PW1, PA1.  A piece is needed 3 phases after it was
 // issued, so loads stay in flight across barriers: every wait is `s_waitcnt vmcnt(4)` (the two youngest pieces may
 // still be flying), never 0, except in the last K-tile.  A piece is read one barrier after the wait that
-// retired it, and overwritten >= 4 phases after its last read.
+// retired it.  Overwrites: PA0 >= 3 phases, PW0 2 phases, PW1 / PA1 >= 4 phases after the rows' last read in a steady
+// K-tile; the last K-tile of an output tile is the tight case and is handled explicitly (k_tile, phase 1): between the
+// last read of a row and the DMA instruction that overwrites it there is always an s_waitcnt lgkmcnt(0) of the reading
+// wave followed by a workgroup barrier.
 // Each phase is two barrier-separated slots.  Waves with wm = 0 do {fragment reads | MFMAs}; waves with wm = 1 run
 // one slot behind, {MFMAs of the previous phase | fragment reads}.  A SIMD hosts one wave of each kind, so its
 // matrix pipe and the LDS pipe are busy in the same slot instead of alternating.  DMA issue (even slots) and
@@ -163,9 +166,14 @@ __device__ __forceinline__ void k_tile(const GemmParams& p, const LoopCtx& c, un
         if constexpr (phase == 1) VMW(15) else if constexpr (phase == 2) VMW(17) else if constexpr (phase == 4) VMW(0) \
     }
     // ---------------- phase 1: A rows [0,64) x W rows [0,32)
-    if constexpr (LEAD) { RD_A(0) RD_W(0) DMA(1) } else if constexpr (!FIRST) { LGKM0; MMA(1, 0) }
+    // KT_LAST: its phase-1 DMA writes W rows [0,32) of the OTHER buffer, which the lag waves read (RD_W(0), phase 4 of the
+    // previous K-tile) one slot earlier and only retire with the LGKM0 that heads this slot.  The lead waves therefore issue
+    // it in their second slot, behind the barrier that follows that LGKM0, so a barrier -- not global-load latency -- orders
+    // the LDS write after the reads.  (Steady K-tiles write PA0 here, rows last read three phases earlier.)
+    constexpr bool LATE_DMA1 = KIND == KT_LAST;
+    if constexpr (LEAD) { RD_A(0) RD_W(0) if constexpr (!LATE_DMA1) { DMA(1) } } else if constexpr (!FIRST) { LGKM0; MMA(1, 0) }
     BAR;
-    if constexpr (LEAD) { LGKM0; MMA(0, 0) } else { RD_A(0) RD_W(0) DMA(1) }
+    if constexpr (LEAD) { LGKM0; MMA(0, 0) if constexpr (LATE_DMA1) { DMA(1) } } else { RD_A(0) RD_W(0) DMA(1) }
     WAIT(1)
     BAR;
     // ---------------- phase 2: A rows [0,64) x W rows [32,64)

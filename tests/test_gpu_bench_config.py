@@ -120,6 +120,96 @@ def test_concurrent_lanes_are_deterministic_at_dim_1024():
     assert bad == 0, f"{bad} / 600 concurrent forwards differ from the sequential result"
 
 
+def test_operator_kernels_are_deterministic_under_concurrent_lanes():
+    """The Section-4a corruption (a LayerNorm row short of a lane's partial sum, only with other kernels co-resident on
+    the CU) was found by a bench self-check, not by a test.  This is the test: every kernel family of the decode loop
+    -- attention (self, and the ragged 77-key cross form), the two-workgroups-per-CU residual GEMM, the 256x256 GEMMs
+    (head split, SwiGLU, plain), LayerNorm, the sampling kernel and the re-mask sort -- at the dim-1024 / 16-head /
+    512-px shapes runs on three streams at once, each stream a different kernel mix, 60 rounds; every result must be
+    bit-identical to the same call on an idle device."""
+    from paintmind_amd import ops
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dev())
+    B, H, N, D = 4, 16, 1024, 1024
+    M = B * N
+    q = rnd(B, H, N, 64, scale=0.6).to(bf); k = rnd(B, H, N, 64).to(bf); vt = rnd(B, H, 64, N).to(bf)
+    kc = rnd(B, H, 128, 64).to(bf); vtc = rnd(B, H, 64, 128).to(bf)                      # context of 77 keys, padded to 128
+    x = rnd(M, D); a = rnd(M, D, scale=0.5).to(bf)
+    wo = rnd(D, D, scale=D ** -0.5).to(bf); bo = rnd(D)
+    wqkv = rnd(3 * D, D, scale=D ** -0.5).to(bf)
+    w12 = rnd(2 * 2752, D, scale=D ** -0.5).to(bf); b12 = rnd(2 * 2752)
+    gamma, beta = 1 + 0.1 * rnd(D), 0.1 * rnd(D)
+    logits = rnd(2048, 8192)
+    ids = torch.randint(0, 8192, (2048,), generator=torch.Generator().manual_seed(5)).to(dev())
+    ids[::2] = 8192
+    scores = rnd(2, 1024)
+
+    def work(i):
+        out = []
+        if i == 0:
+            out.append(ops.attention(q, k, vt, N, use_exp2=True))
+            out.append(ops.gemm(a, wo, bias=bo, residual=x, out_dtype=torch.float32))      # K = 1024 residual GEMM: 256x256 kernel
+            out.append(ops.layernorm(x, gamma, beta, out_dtype=bf))
+            out += list(ops.sample_rows(logits, ids, 8192, 5, 0.7, seed=3, step=2))
+        elif i == 1:
+            out += list(ops.gemm_heads(a, wqkv, H, N, [ops.PART_Q, ops.PART_K, ops.PART_V], 0.125))
+            out.append(ops.attention(q, kc, vtc, 77, use_exp2=True))
+            out.append(ops.gemm(a[:, :512].contiguous(), wo[:, :512].contiguous(), bias=bo, residual=x, out_dtype=torch.float32))   # K = 512: gemm2b
+            r = ids.reshape(2, 1024).clone()
+            out.append(ops.remask(r, scores, 300, 8192))
+        else:
+            out.append(ops.gemm_swiglu(a, w12, b12))
+            out.append(ops.layernorm(x, gamma, beta, out_dtype=bf))
+            out.append(ops.attention(q, k, vt, N, use_exp2=True))
+            out.append(ops.gemm(a, wqkv[: 2 * D].contiguous(), out_dtype=bf))
+        return out
+
+    ref = [work(i) for i in range(3)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    bad = []
+    for rep in range(60):
+        res = []
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                res.append(work((i + rep) % 3))
+        torch.cuda.synchronize()
+        for i in range(3):
+            for j, (got, want) in enumerate(zip(res[i], ref[(i + rep) % 3])):
+                if not torch.equal(got, want):
+                    bad.append((rep, (i + rep) % 3, j))
+    assert not bad, f"{len(bad)} results differ under concurrency, first {bad[:5]}"
+
+
+@pytest.mark.parametrize("name,B,T,L", [("bench-text-24L-d768", 8, 12, 77), ("bench-text-24L-d1024-512px", 8, 18, 77)])
+def test_configs_4_and_5_graph_and_lanes_bit_identical_to_eager(name, B, T, L):
+    """BASELINE configs[3] (T = 12) and configs[4] (vit-b 512 px, d1024, T = 18) at their full step counts, B = 8: segment
+    graphs + two / three lanes against the eager single-stream loop, ids and every decoded image bit for bit
+    (reference generate.py:183-198: one code path)."""
+    torch.manual_seed(0)
+    pipe = Pipeline(pm.Config(ver2cfg[name]), stage1_pretrained=False).to(dev()).eval()
+    ctx = torch.randn(B, L, ver2cfg[name]["context_dim"], generator=torch.Generator().manual_seed(1234)).to(dev())
+    flags = [step % 2 == 0 for step in range(T)]                # the reference's default save_interval
+    pipe.set_compute_dtype(torch.bfloat16)
+    try:
+        eager = {}
+        for seed in (7, 8):
+            ids, imgs = pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=seed, use_graph=False, streams=1)
+            eager[seed] = (ids.clone(), imgs.clone())
+            assert torch.isfinite(imgs).all() and int((ids == pipe.mask_token_id).sum(1).max()) == 1
+        for lanes in (2, 3):
+            for seed in (7, 8, 7):                              # eager warm-up of the graph path, capture, replay
+                ids, imgs = pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=seed, use_graph=True, streams=lanes)
+                torch.cuda.synchronize()
+                assert torch.equal(ids, eager[seed][0]), (name, lanes, seed)
+                assert torch.equal(imgs, eager[seed][1]), (name, lanes, seed)
+    finally:
+        pipe.set_compute_dtype(torch.float32)
+        del pipe
+        torch.cuda.empty_cache()
+
+
 def test_layernorm_fold_option_full_size(pipe512, monkeypatch):
     """PMHIP_LN_FOLD=1 (opt-in): the LayerNorm passes disappear into the GEMMs either side (432 -> 8 launches per bench
     step).  Same maths up to bf16 rounding of the raw residual row instead of the normalised row: the folded bf16

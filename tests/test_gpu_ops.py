@@ -97,6 +97,20 @@ def test_swiglu_and_heads_large_tile_kernel():
     assert rel_err(n(vt), full[:, :, 2].transpose(0, 2, 3, 1)) < 1e-2
 
 
+def test_gemm_stats_without_residual_on_a_large_tile_shape():
+    """pmhip_gemm_stats with residual == NULL on a shape the 256x256 / two-workgroup kernels would take: those only emit the
+    bf16 copy and the statistics from their residual epilogue, so the request must be served by the kernel that handles it
+    (round-2 advisor finding: the outputs stayed unwritten)."""
+    M, D, K0 = 65536 // 8, 512, 512
+    bf = torch.bfloat16
+    a, w0, b0 = bf16_round(rnd(M, K0)), bf16_round(rnd(D, K0, scale=K0 ** -0.5)), rnd(D)
+    out, xb, stats = ops.gemm_stats(t(a, bf), t(w0, bf), bias=t(b0), residual=None)
+    plain = ops.gemm(t(a, bf), t(w0, bf), bias=t(b0), out_dtype=torch.float32)
+    assert torch.equal(out, plain) and torch.equal(xb, out.to(bf))
+    x = n(out).astype(np.float64).reshape(M, D // 64, 64)
+    assert rel_err(n(stats)[..., 0].T, x.sum(-1)) < 1e-5 and rel_err(n(stats)[..., 1].T, (x ** 2).sum(-1)) < 1e-5
+
+
 def test_layernorm_fold_producer_and_consumers():
     """LayerNorm folded into its neighbour GEMMs (stage1/layers.py:54-58: every projection consumes LN(x)).
     Producer: the residual GEMM also emits bf16(x) and the per-64-column (sum, sum of squares) partials -- the f32 result
