@@ -480,9 +480,12 @@ def main():
     B = WORKLOADS[args.workload][1]
 
     recv = {}                                    # rank 0: receive buffers per (lane, shape), allocated once
+    inflight = []                                # (work handle, tensor) of gathers not yet waited for
 
-    def gather(last, lane=0):
-        """the path's only collective: finished images -> rank 0 (RCCL gather on the calling stream)"""
+    def gather(last, lane=0, asynchronous=False):
+        """the path's only collective: finished images -> rank 0.  RCCL runs it on the process group's own stream, ordered
+        after the calling stream's work so far.  asynchronous: the calling stream does NOT wait for the collective (the lane
+        goes straight on with its next replay); the handle is waited for once, before the closing synchronize."""
         if dist is None:
             return last
         bufs = None
@@ -491,15 +494,23 @@ def main():
             if key not in recv:
                 recv[key] = [torch.empty_like(last) for _ in range(world)]
             bufs = recv[key]
-        dist.gather(last, bufs, dst=0)
+        if asynchronous:
+            inflight.append((dist.gather(last, bufs, dst=0, async_op=True), last))
+        else:
+            dist.gather(last, bufs, dst=0)
         return last
 
     def gather_lanes(parts):
-        """free-running lanes: every lane hands its finished images to the gather on ITS stream, in lane order on all
-        ranks; the lane's next replay is ordered after its gather by the stream, nothing waits on the host"""
+        """free-running lanes: every lane hands its finished images to an asynchronous gather (issued in lane order on all
+        ranks, ordered after the lane's stream); no lane and no host thread waits for RCCL inside the loop"""
         for lane, (_, imgs, st) in enumerate(parts):
             with torch.cuda.stream(st):
-                gather(imgs[-1], lane)
+                gather(imgs[-1], lane, asynchronous=True)
+
+    def drain_gathers():
+        for work, _ in inflight:
+            work.wait()
+        inflight.clear()
 
     # one-time setup, not a benchmark step: the first two calls size the workspaces and capture the decode-loop
     # graph of every lane (eager pass, capture pass); afterwards every call is a pure replay
@@ -530,6 +541,7 @@ def main():
             gather_lanes(step(i, join=False))           # same code path as the timed loop (RCCL init, receive buffers)
         else:
             gather(step(i))
+    drain_gathers()
     log("timed region")
     if dist is not None:
         dist.barrier()
@@ -542,6 +554,8 @@ def main():
                 gather_lanes(parts)
         else:
             gather(step(args.warmup + i))
+    host_enqueue = time.perf_counter() - t0             # host time to enqueue all K steps (the GPU is still running them)
+    drain_gathers()
     torch.cuda.synchronize(device)
     own_elapsed = time.perf_counter() - t0              # this rank's own K steps (before waiting for the slowest rank)
     if dist is not None:
@@ -572,6 +586,9 @@ def main():
         "self_check": "ok", "self_check_detail": detail,
         "rccl_ranks": dist.get_world_size() if dist is not None else 0,
         "per_rank_images_per_s": [round(B * args.steps / e, 3) for e in per_rank],
+        # host time this rank spent launching one step (graph replays, parameter copy, gather issue); the rest of
+        # ms_per_step the host only waits, so 8 ranks on one node do not compete for host cores
+        "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
     }
 
     log(f"timed region done: {ms_per_step:.1f} ms/step")

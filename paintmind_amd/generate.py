@@ -193,13 +193,20 @@ class Pipeline(nn.Module):
             text = self.text_model(text)
         return x, indices, text
 
+    def _on_cpu(self):
+        return self.mask_token.device.type == "cpu"
+
     def tokens2logits(self, token, text=None):
+        if self._on_cpu():
+            return self.transformer(token, text)             # plain-torch operators of this package (no HIP engine on the CPU)
         return self.engine().forward(token, text)
 
     @torch.no_grad()
     def ids2tokens(self, ids):
         """lookup in cat(RAW codebook, mask_token) (generate.py:148-157)."""
         table = torch.cat((self.vqgan.quantize.embedding.weight.data.float(), self.mask_token.data.float())).contiguous()
+        if self._on_cpu():
+            return table[ids]
         rows = ops.embed_rows(table, ids.contiguous().reshape(-1), table.shape[1], torch.float32)
         return rows.reshape(ids.shape + (table.shape[1],))
 
@@ -214,6 +221,8 @@ class Pipeline(nn.Module):
         (generate.py:40-46), so a caller looping over sample() never reuses uniforms.
         """
         nm = num_token_masked(mask_ratio, self.num_tokens)
+        if self._on_cpu():
+            return self._sample_cpu(ids, nm, text, topk, temperature, noise, seed)
         if seed is None:
             seed = _draw_seed()
         eng = self.engine()
@@ -221,6 +230,38 @@ class Pipeline(nn.Module):
         ids, img, _, _ = eng.sample(self.vqgan.engine(), ids, text, topk, temperature, nm, noise=noise, seed=seed, step=step,
                                     image_base=image_base, want_img=True)
         return ids, img
+
+    def _sample_cpu(self, ids, nm, text, topk, temperature, noise, seed):
+        """generate.py:159-181 in plain torch for a pipeline that lives on the CPU.  The noise is drawn from the torch CPU
+        generator like the reference's (`seed` re-seeds a private generator; `noise` overrides it); ties in top-k / argmax
+        follow torch."""
+        logits = self.tokens2logits(self.ids2tokens(ids), text)
+        val, ind = logits.topk(topk, dim=-1)
+        filtered = torch.full_like(logits, float("-inf")).scatter_(2, ind, val)
+        if noise is None:
+            g = None if seed is None else torch.Generator().manual_seed(int(seed) & (2 ** 63 - 1))
+            noise = torch.rand(logits.shape, generator=g)
+        gumbel = -torch.log((-torch.log(noise.clamp(min=1e-20))).clamp(min=1e-20))
+        pred = (filtered / max(temperature, 1e-10) + gumbel).argmax(dim=-1)
+        img = self.vqgan.decode_from_indice(pred)            # decoded from the predictions at ALL positions (:165)
+        is_mask = ids == self.mask_token_id
+        ids = torch.where(is_mask, pred, ids)
+        scores = 1 - logits.softmax(dim=-1).gather(2, pred[..., None])[..., 0]
+        scores = scores.masked_fill(~is_mask, -1e5)
+        ids = ids.scatter(1, scores.topk(nm, dim=-1).indices, self.mask_token_id)
+        return ids, img
+
+    def _generate_cpu(self, text, context, timesteps, temperature, topk, save_interval, seed, return_ids):
+        B = len(text)
+        ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long)
+        imgs = []
+        for step in range(timesteps):
+            masked_r = mask_schedule((step + 1) / timesteps)
+            ids, img = self._sample_cpu(ids, num_token_masked(masked_r, self.num_tokens), context, topk,
+                                        temperature * (1 - step / timesteps), None, None if seed is None else seed + step)
+            if step % save_interval == 0:
+                imgs.append(img)
+        return (imgs, ids) if return_ids else imgs
 
     def _schedule(self, timesteps, temperature):
         temps, nmask = [], []
@@ -332,6 +373,8 @@ class Pipeline(nn.Module):
         results are bit-identical for every setting (tests/test_gpu_model.py)."""
         B = len(text)
         context = self.text_model(text)
+        if self._on_cpu():
+            return self._generate_cpu(text, context, timesteps, temperature, topk, save_interval, seed, return_ids)
         eng = self.engine()
         if seed is None:
             seed = _draw_seed()

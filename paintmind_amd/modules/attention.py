@@ -10,6 +10,7 @@ softmax(QK^T)V that never materialises the score matrix, and an out-projection w
 (+ residual when called from a Layer).
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import ops, packing
@@ -61,6 +62,8 @@ class CrossAttention(nn.Module):
         """x [B,N,query_dim]; returns to_out(attn) (+ residual) as fp32/bf16 like x."""
         if self.training and self.to_out[1].p > 0:
             raise RuntimeError("paintmind_amd attention is inference-only (dropout>0 in training mode)")
+        if not x.is_cuda:
+            return self._run_cpu(x, context, residual)
         B, N, D = x.shape
         dtype = x.dtype
         pk = self.packed(dtype)
@@ -83,6 +86,21 @@ class CrossAttention(nn.Module):
         out_dtype = torch.float32 if residual is not None else dtype
         out = ops.gemm(o, pk["wo"], bias=pk["bo"], residual=res, out_dtype=out_dtype)
         return out.reshape(B, N, D)
+
+
+    def _run_cpu(self, x, context, residual):
+        """Parameters on the CPU: the same operator in plain torch (reference modules/attention.py:43-59; BASELINE config 1
+        runs the model there).  q is scaled BEFORE the product (:52), no mask, softmax over the keys, head split 'b n (h d)'."""
+        B, N, _ = x.shape
+        c = x if context is None else context
+        h, d = self.heads, self.dim_head
+        q = (F.linear(x, self.to_q.weight) * self.scale).reshape(B, N, h, d).permute(0, 2, 1, 3)
+        k = F.linear(c, self.to_k.weight).reshape(B, c.shape[1], h, d).permute(0, 2, 1, 3)
+        v = F.linear(c, self.to_v.weight).reshape(B, c.shape[1], h, d).permute(0, 2, 1, 3)
+        p = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+        o = (p @ v).permute(0, 2, 1, 3).reshape(B, N, h * d)
+        out = F.linear(o, self.to_out[0].weight, self.to_out[0].bias)
+        return out if residual is None else out + residual
 
 
 def round_up64(v):

@@ -5,6 +5,7 @@ arithmetic is one GEMM whose epilogue applies silu(x1)*x2 (so the 2*hidden-wide 
 reaches HBM) followed by the w3 GEMM with fused bias (+ residual when called from a Layer).
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import ops, packing
@@ -37,6 +38,11 @@ class SwiGLUFFN(nn.Module):
         return self.run(x, residual=None)
 
     def run(self, x, residual=None):
+        if not x.is_cuda:
+            # parameters on the CPU: plain torch (reference modules/mlp.py:27-31: the FIRST half of w12's output is gated)
+            x1, x2 = F.linear(x, self.w12.weight, self.w12.bias).chunk(2, dim=-1)
+            out = F.linear(F.silu(x1) * x2, self.w3.weight, self.w3.bias)
+            return out if residual is None else out + residual
         shape = x.shape
         dtype = x.dtype
         pk = self.packed(dtype)

@@ -6,6 +6,7 @@ below compose the HIP operators one call at a time (the "operator plug-in" view 
 ``VQModel.encode/decode`` use the fused C++ engine instead, and tests pin the two against each other.
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import ops, packing
@@ -31,6 +32,8 @@ def _xavier_like_reference(root):
 
 
 def _norm(x2d, ln, out_dtype):
+    if not x2d.is_cuda:                     # CPU branch: torch's own LayerNorm, fp32
+        return F.layer_norm(x2d, (x2d.shape[-1],), ln.weight, ln.bias, ln.eps)
     return ops.layernorm(x2d, ln.weight.detach(), ln.bias.detach(), ln.eps, out_dtype)
 
 
@@ -86,6 +89,10 @@ class Encoder(nn.Module):
         conv = self.to_patch_embedding[0]
         B = img.shape[0]
         dim = conv.out_channels
+        if not img.is_cuda:
+            # CPU branch (reference stage1/layers.py:106-112): conv, 'b c h w -> b (h w) c', + pos, norm_pre, layers
+            x = conv(img.float()).flatten(2).transpose(1, 2) + self.position_embedding
+            return self.transformer(self.norm_pre(x))
         a = ops.patchify(img.contiguous().float(), self.patch_size, T)
         w = packing.cast(conv.weight.reshape(dim, -1), T)
         pos = self.position_embedding.detach()[0].contiguous()
@@ -111,6 +118,11 @@ class Decoder(nn.Module):
         """x fp32 [B,N,dim] (post_quant output) -> un-clamped image [B,C,H,W] (layers.py:145-152)."""
         T = compute_dtype_of(self)
         B, N, D = x.shape
+        if not x.is_cuda:
+            # CPU branch (reference stage1/layers.py:145-152): + pos, layers, norm, proj, 'b (h w) (p1 p2 c) -> b c (h p1) (w p2)'
+            y = self.proj(self.norm(self.transformer(x.float() + self.position_embedding)))
+            g, P, C = self.image_size // self.patch_size, self.patch_size, self.out_channels
+            return y.reshape(B, g, g, P, P, C).permute(0, 5, 1, 3, 2, 4).reshape(B, C, g * P, g * P)
         pos = self.position_embedding.detach()[0].contiguous()
         x = ops.add_rows(x.contiguous().float().reshape(B * N, D), pos).reshape(B, N, D)
         x = self.transformer(x)

@@ -59,12 +59,21 @@ class VQModel(nn.Module):
         for param in self.parameters():
             param.requires_grad = False
 
+    def _on_cpu(self):
+        return self.prev_quant.weight.device.type == "cpu"
+
     @torch.no_grad()
     def encode(self, x):
+        if self._on_cpu():
+            # the module lives on the CPU (BASELINE config 1, reference stage1/vqmodel.py:21-25): plain-torch operators of
+            # this package, fp32; the HIP engine is for ROCm devices only
+            return self.quantize(self.prev_quant(self.encoder(x.to("cpu", torch.float32))))
         return self.engine().encode(x)                      # (z + (z_q - z), loss, indices)
 
     @torch.no_grad()
     def decode(self, x):
+        if self._on_cpu():
+            return self.decoder(self.post_quant(x.to("cpu", torch.float32))).clamp(-1.0, 1.0)    # vqmodel.py:27-30
         return self.engine().decode(x)                      # clamped to [-1, 1]
 
     def forward(self, img):
@@ -73,6 +82,8 @@ class VQModel(nn.Module):
 
     @torch.no_grad()
     def decode_from_indice(self, indice):
+        if self._on_cpu():
+            return self.decode(self.quantize.decode_from_indice(indice.to("cpu")))               # vqmodel.py:38-41
         return self.engine().decode_indices(indice)
 
     def from_pretrained(self, path):

@@ -50,6 +50,15 @@ class CondTransformer(nn.Module):
         T = compute_dtype_of(self)
         B, N, E = x.shape
         dim = self.token_proj.out_features
+        if not x.is_cuda:
+            # parameters on the CPU (reference stage2/transformer.py:80-93 in plain torch): the context is projected once
+            # per forward, a missing context makes attn2 a second self-attention
+            h = self.token_proj(x.float()) + self.position_embedding
+            if context is not None:
+                context = self.context_proj(context.float())
+            for layer in self.layers:
+                h = layer(h, context)
+            return self.to_logits(self.norm(h))
         a = ops.convert_pad(x.contiguous().float().reshape(B * N, E), 64, T)
         pos = self.position_embedding.detach()[0].contiguous()
         h = ops.gemm(a, packing.pad_cols(self.token_proj.weight, 64, T), bias=self.token_proj.bias.detach().float(),

@@ -35,14 +35,19 @@ def test_errors_are_reported_not_thrown():
     assert rc == 1
 
 
-def test_no_cpu_fallback():
-    torch.manual_seed(0)
-    m = pm.create_model(arch="vqgan", version="tiny-vqgan", pretrained=False)
-    with pytest.raises(_lib.PmhipError):
-        m.encode(torch.zeros(1, 3, 32, 32))
+def test_hip_operators_have_no_cpu_fallback():
+    """The HIP operators never compute on the CPU: a CPU tensor handed to one raises.  (A MODULE that lives on the CPU is a
+    different matter: it runs this package's own plain-torch branch, like the reference runs on whatever device the module is
+    on -- tests/test_cpu_branch.py.)"""
     from paintmind_amd import ops
     with pytest.raises(_lib.PmhipError):
         ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64))
+    with pytest.raises(_lib.PmhipError):
+        ops.gemm(torch.zeros(128, 64), torch.zeros(128, 64))
+    torch.manual_seed(0)
+    m = pm.create_model(arch="vqgan", version="tiny-vqgan", pretrained=False)
+    with pytest.raises(_lib.PmhipError):
+        m.engine()                                   # the native engine itself is for ROCm devices only
 
 
 def test_factory_surface():
@@ -81,7 +86,7 @@ def test_pipeline_wiring_and_schedule():
     assert nm == api_facts()["mask_counts_T8_N1024"]
     temps, nmask = p._schedule(8, 1.0)
     assert temps[0] == 1.0 and temps[-1] == 0.125 and nmask[-1] == 1
-    with pytest.raises(_lib.PmhipError):            # forward (masked-token loss) has no CPU fallback either
+    with pytest.raises(_lib.PmhipError):            # the masked-token objective (forward) is HIP-only: no CPU branch
         p(torch.zeros(1, 3, 32, 32))
 
 
