@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PMHIP_ABI_VERSION 5
+#define PMHIP_ABI_VERSION 6
 
 enum { PMHIP_OK = 0, PMHIP_EINVAL = 1, PMHIP_EHIP = 2, PMHIP_ENOMEM = 3, PMHIP_ESTATE = 4 };
 enum { PMHIP_F32 = 0, PMHIP_BF16 = 1 };
@@ -69,28 +69,41 @@ int pmhip_gemm_heads(int dtype, const void* A, int lda, const void* W, int ldw, 
                      int heads, int tokens, int tokens_pad, int nparts, const int* part_kinds_host,
                      void* const* part_outs_host, float q_scale, pmhip_stream stream);
 
-/* ---- LayerNorm folded into the GEMMs either side of it (bf16 mode; stage1/layers.py:54-58, stage2/transformer.py:44-49:
- * every projection is preceded by a LayerNorm of the residual stream).  y = LN(x) = (x - mean) * rstd * gamma + beta, so
- *     y . W^T = rstd * (x . (gamma (.) W)^T) - rstd * mean * c + d,   c[n] = sum_k gamma[k] W[n,k],  d[n] = sum_k beta[k] W[n,k].
- * The GEMM that PRODUCES x (a residual GEMM) also writes x as bf16 and, per row and 64-column chunk, (sum x, sum x^2);
- * the GEMM that CONSUMES LN(x) multiplies the raw bf16 x by the gamma-scaled weights and applies the formula in its
- * epilogue.  The separate LayerNorm pass (read 4 B + write 2 B per element) disappears.  Deterministic: no atomics. */
+/* ---- bf16 mode: the residual stream as a bf16 PAIR, and the LayerNorm folded into the GEMM that consumes it
+ * (stage1/layers.py:54-58, stage2/transformer.py:44-49: x = f(LN(x)) + x, every projection preceded by a LayerNorm).
+ * x = hi + lo with hi = bf16(x), lo = bf16(x - hi): two bf16 planes [M, D] -- the same 4 bytes per element as fp32 and, for a
+ * stream built by adding bf16-GEMM outputs, the same accuracy (tools/residual_precision_probe.py: logits identical to the
+ * fp32 stream to 5e-4, against +65 % error for a single bf16 plane).  What it buys: the hi plane IS bf16(x), the operand of
+ * the next projection, so with  y = LN(x) = (x - mean) * rstd * gamma + beta  and
+ *     y . W^T = rstd * (x . (gamma (.) W)^T) - rstd * mean * c + d,   c[n] = sum_k gamma[k] W[n,k],  d[n] = sum_k beta[k] W[n,k]
+ * the projection multiplies hi by gamma-scaled weights and normalises in its epilogue; the separate LayerNorm pass over
+ * the stream (read 4 B + write 2 B per element, 21 % of the GPU time of a decode step in round 2) is replaced by
+ * pmhip_ln_coef, which reads the hi plane only.  Deterministic: no atomics. */
+
+/* (hi, lo) <- split(A[M,K] . W[N,K]^T + bias + (res_hi + res_lo)[m % res_rows]); bf16 operands.  In place when the output
+ * planes are the residual planes.  N, ldr, ldo multiples of 8. */
+int pmhip_gemm_hilo(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
+                    const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N,
+                    int K, pmhip_stream stream);
+/* row operators on the pair (D a multiple of 4, <= 1024): LayerNorm of hi + lo -> f32 / bf16 (the unfolded path);
+ * LayerNorm of an f32 row -> hi, lo; f32 -> hi, lo and back */
+int pmhip_layernorm_hilo(const void* x_hi, const void* x_lo, const float* gamma, const float* beta, float eps,
+                         void* out, int out_dtype, int M, int D, pmhip_stream stream);
+int pmhip_layernorm_to_hilo(const float* x, const float* gamma, const float* beta, float eps, void* out_hi,
+                            void* out_lo, int M, int D, pmhip_stream stream);
+int pmhip_split_hilo(const float* x, void* out_hi, void* out_lo, int M, int D, pmhip_stream stream);
+int pmhip_join_hilo(const void* x_hi, const void* x_lo, float* out, int M, int D, pmhip_stream stream);
+/* coef[M][2] = (rstd, -rstd * mean) of the rows of the hi plane (two-pass, like the LayerNorm kernel) */
+int pmhip_ln_coef(const void* x_hi, float eps, float* coef, int M, int D, pmhip_stream stream);
+
 typedef struct pmhip_lnfold {
-    const float* stats;   /* [K/64][M][2] (chunk-major): per 64-column chunk and row (sum x, sum x^2), written by pmhip_gemm_stats */
+    const float* coef;    /* [M][2]: (rstd, -rstd * mean) per row, from pmhip_ln_coef */
     const float* c;       /* [N]: sum_k of the (rounded) gamma-scaled weight row */
     const float* d;       /* [N]: sum_k beta[k] * W[n,k] */
-    float eps;            /* LayerNorm eps */
-    float* coef;          /* scratch [M][2]: the consumer entry point reduces `stats` to (rstd, -rstd * mean) per row here (one
-                             small kernel, chunk order: deterministic) before its GEMM */
 } pmhip_lnfold;
 
-/* pmhip_gemm with an f32 result that ALSO emits xb_out[M,N] (bf16 copy, row stride ldxb) and stats_out[N/64][M][2].
- * N must be a multiple of 64. */
-int pmhip_gemm_stats(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
-                     const float* residual, int ldr, int res_rows, float* out, int ldo, void* xb_out,
-                     int ldxb, float* stats_out, int M, int N, int K, pmhip_stream stream);
-/* Consumers: same arguments as pmhip_gemm (no residual) / pmhip_gemm_swiglu / pmhip_gemm_heads, with A = the raw bf16
- * rows, W = the gamma-scaled weights and `ln` the fold descriptor.  Only shapes served by the 256x256 kernel
+/* Consumers: same arguments as pmhip_gemm (no residual) / pmhip_gemm_swiglu / pmhip_gemm_heads, with A = the hi plane,
+ * W = the gamma-scaled weights and `ln` the fold descriptor.  Only shapes served by the 256x256 kernel
  * (pmhip_lnfold_supported; epi_kind 0 = plain, 1 = SwiGLU, 2 = head split; N counts the packed output rows). */
 int pmhip_gemm_ln(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
                   int ldo, int out_dtype, int M, int N, int K, const pmhip_lnfold* ln, pmhip_stream stream);

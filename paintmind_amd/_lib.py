@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpaintmind_hip.so")
 PMHIP_OK = 0
 F32, BF16 = 0, 1
 PART_Q, PART_K, PART_V = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 vp = C.c_void_p
 i32 = C.c_int
@@ -60,7 +60,7 @@ class S2Weights(C.Structure):
 
 class LnFold(C.Structure):
     """mirror of pmhip_lnfold"""
-    _fields_ = [("stats", vp), ("c", vp), ("d", vp), ("eps", f32), ("coef", vp)]
+    _fields_ = [("coef", vp), ("c", vp), ("d", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/pmhip.h declares
@@ -72,7 +72,12 @@ PROTOTYPES = {
     "pmhip_gemm_swiglu": (i32, [i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "pmhip_gemm_heads": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32),
                                C.POINTER(vp), f32, vp]),
-    "pmhip_gemm_stats": (i32, [i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
+    "pmhip_gemm_hilo": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "pmhip_layernorm_hilo": (i32, [vp, vp, vp, vp, f32, vp, i32, i32, i32, vp]),
+    "pmhip_layernorm_to_hilo": (i32, [vp, vp, vp, f32, vp, vp, i32, i32, vp]),
+    "pmhip_split_hilo": (i32, [vp, vp, vp, i32, i32, vp]),
+    "pmhip_join_hilo": (i32, [vp, vp, vp, i32, i32, vp]),
+    "pmhip_ln_coef": (i32, [vp, f32, vp, i32, i32, vp]),
     "pmhip_gemm_ln": (i32, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, C.POINTER(LnFold), vp]),
     "pmhip_gemm_swiglu_ln": (i32, [i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, C.POINTER(LnFold), vp]),
     "pmhip_gemm_heads_ln": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32),

@@ -64,8 +64,6 @@ struct PmGenParams {
     float temps[PM_MAX_STEPS];
     int nmask[PM_MAX_STEPS];
 };
-// LayerNorm fold: stats[nc][M][2] (per 64-column chunk: sum x, sum x^2) -> coef[M][2] = (rstd, -rstd * mean); chunk order
-int pm_ln_finalize(const float* stats, int nc, int M, float eps, float* coef, pmhip_stream stream);
 int pm_sample_rows(const float* logits, int ldl, const int64_t* ids_in, int64_t mask_id, int topk, float temperature,
                    const float* noise, uint64_t seed, uint32_t step, uint64_t row_base, int64_t* pred_out, int64_t* ids_out,
                    float* score_out, int M, int V, const PmGenParams* gp, pmhip_stream stream);

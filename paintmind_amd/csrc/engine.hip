@@ -140,22 +140,30 @@ struct CrossKV {            // cached cross-attention K / V^T of a static contex
 };
 
 struct TowerBufs {
-    float* x = nullptr;     // residual stream, fp32 [M, dim]
-    void* y = nullptr;      // normed activations, T [M, dim]
+    float* x = nullptr;     // residual stream, fp32 [M, dim]                      (fp32-verify mode)
+    void* xh = nullptr;     // residual stream as a bf16 pair: x = hi + lo, [M, dim] each   (bf16-perf mode).  The hi plane IS
+    void* xl = nullptr;     //   bf16(x): the operand of every GEMM that consumes LN(x) with the LayerNorm folded in
+    void* y = nullptr;      // normed activations, T [M, dim] (unfolded LayerNorm output)
     void* q = nullptr; void* k = nullptr; void* vt = nullptr;
     void* attn = nullptr;   // T [M, inner]
     void* hid = nullptr;    // T [M, hidden_pad]
     float* split = nullptr; // dim_head != 64 only: f32 scratch of the plain head-split path [M, 3*inner]
-    float* coef = nullptr;  // LayerNorm fold: per-row (rstd, -rstd * mean) scratch of the consumer
-    float* stats = nullptr; // LayerNorm fold: per row and 64-column chunk (sum x, sum x^2) of the residual stream
-    // LayerNorm fold state of one forward pass.  fold: the handle is in bf16 mode and folding is enabled; stats_valid:
-    // `stats` and the bf16 copy of x (kept in `y`) describe the CURRENT x (its producer was a GEMM that emitted them)
-    bool fold = false, stats_valid = false;
+    float* coef = nullptr;  // LayerNorm fold: per-row (rstd, -rstd * mean) of the hi plane
+    bool hilo = false;      // bf16 mode
+    bool fold = false;      // hilo and folding not disabled (PMHIP_LN_UNFOLD=1 forces the separate LayerNorm kernel: A/B tests)
 };
 
-// The LayerNorm fold is OPT-IN (PMHIP_LN_FOLD=1, read on every forward so that tests can switch it): it removes the
-// LayerNorm launches (432 -> 8 per bench step) but costs the consumer GEMMs ~1-2 us per tile, and with three concurrent
-// lanes the HBM-bound LayerNorm already hides under the other lanes' GEMMs: measured 401 vs 410 images/s.
+// where a residual GEMM takes its addend from: fp32 rows (verify mode), or a pair of bf16 planes (bf16 mode)
+struct ResSrc {
+    const float* f32 = nullptr;
+    const void* hi = nullptr; const void* lo = nullptr;
+    int ld = 0, rows = 0;      // row stride; rows > 0: the addend row is m % rows (position embedding)
+};
+
+// bf16 mode: the LayerNorm that precedes every projection (stage1/layers.py:54-58, stage2/transformer.py:44-49) is folded into
+// that projection wherever the 256x256 kernel serves the shape: the consumer multiplies the hi plane by gamma-scaled weights
+// and normalises in its epilogue with the row's (rstd, -rstd * mean) from pmhip_ln_coef.  Elsewhere (small batches, the
+// decoder's 192-wide projection) pmhip_layernorm_hilo writes LN(x) and the plain GEMM runs.
 inline int dh_of(const pmhip_tower_cfg& tc) { return tc.dim_head > 0 ? tc.dim_head : 64; }
 
 int check_dim_head(const char* who, const pmhip_tower_cfg& tc) {
@@ -166,8 +174,8 @@ int check_dim_head(const char* who, const pmhip_tower_cfg& tc) {
 }
 
 bool ln_fold_enabled() {
-    const char* e = getenv("PMHIP_LN_FOLD");
-    return e && atoi(e) != 0;
+    const char* e = getenv("PMHIP_LN_UNFOLD");
+    return !(e && atoi(e) != 0);
 }
 
 int alloc_tower(Workspace& ws, const char* tag, int dtype, const pmhip_tower_cfg& tc, int B, int tokens, TowerBufs& b,
@@ -176,45 +184,65 @@ int alloc_tower(Workspace& ws, const char* tag, int dtype, const pmhip_tower_cfg
     const size_t M = (size_t)B * tokens;
     const int dh = dh_of(tc), inner = tc.heads * dh, Np = round_up(tokens, 64);
     std::string t(tag);
-    WS(ws, (t + ".x").c_str(), M * tc.dim * 4, b.x);
+    // development switch for same-box comparisons: PMHIP_F32_STREAM=1 keeps the fp32 residual stream + LayerNorm kernel of
+    // rounds 1-2 in bf16 mode
+    static int f32_stream = -1;
+    if (f32_stream < 0) { const char* e = getenv("PMHIP_F32_STREAM"); f32_stream = e ? atoi(e) : 0; }
+    b.hilo = dtype == PMHIP_BF16 && !f32_stream;
+    if (b.hilo) {
+        WS(ws, (t + ".xh").c_str(), M * tc.dim * 2, b.xh);
+        WS(ws, (t + ".xl").c_str(), M * tc.dim * 2, b.xl);
+    } else {
+        WS(ws, (t + ".x").c_str(), M * tc.dim * 4, b.x);
+    }
     WS(ws, (t + ".y").c_str(), M * tc.dim * es, b.y);
     WS(ws, (t + ".q").c_str(), (size_t)B * tc.heads * tokens * dh * es, b.q);
     WS(ws, (t + ".k").c_str(), (size_t)B * tc.heads * Np * dh * es, b.k);
     WS(ws, (t + ".vt").c_str(), (size_t)B * tc.heads * Np * dh * es, b.vt);
     WS(ws, (t + ".attn").c_str(), M * inner * es, b.attn);
     WS(ws, (t + ".hid").c_str(), M * tc.hidden_pad * es, b.hid);
-    WS(ws, (t + ".stats").c_str(), M * (tc.dim / 64) * 2 * 4, b.stats);
     WS(ws, (t + ".coef").c_str(), M * 2 * 4, b.coef);
     b.split = nullptr;
     if (dh != 64) WS(ws, (t + ".split").c_str(), M * 3 * inner * 4, b.split);
-    b.fold = dtype == PMHIP_BF16 && dh == 64 && ln_fold_enabled();
-    b.stats_valid = false;
+    b.fold = b.hilo && dh == 64 && ln_fold_enabled();
     return PMHIP_OK;
 }
 
-// residual GEMM x = A . W^T + bias + residual (in place when residual == b.x).  With the fold on it also emits the bf16
-// copy of x into b.y and the row statistics, which lets the NEXT LayerNorm disappear into its consumer.
-int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual,
-                  int ldr, int res_rows, int M, int N, int K, hipStream_t s) {
-    if (b.fold && N % 64 == 0) {
-        PM_TRY(pmhip_gemm_stats(dtype, A, lda, W, ldw, bias, residual, ldr, res_rows, b.x, N, b.y, N, b.stats, M, N, K, s));
-        b.stats_valid = true;
-        return PMHIP_OK;
-    }
-    b.stats_valid = false;
-    return pmhip_gemm(dtype, A, lda, W, ldw, bias, residual, ldr, res_rows, b.x, N, PMHIP_F32, M, N, K, s);
+// the residual stream itself as the addend (x += ...)
+ResSrc res_self(const TowerBufs& b, int dim) {
+    ResSrc r;
+    r.f32 = b.x; r.hi = b.xh; r.lo = b.xl; r.ld = dim; r.rows = 0;
+    return r;
 }
 
-// LN(x) -> head-split projection: folded when the statistics of x are at hand and the shape is served, else LayerNorm + GEMM
+// residual GEMM x = A . W^T + bias + addend, written to the tower's residual stream (in place when the addend is the stream)
+int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W, int ldw, const float* bias, const ResSrc& r,
+                  int M, int N, int K, hipStream_t s) {
+    if (b.hilo) return pmhip_gemm_hilo(A, lda, W, ldw, bias, r.hi, r.lo, r.ld, r.rows, b.xh, b.xl, N, M, N, K, s);
+    return pmhip_gemm(dtype, A, lda, W, ldw, bias, r.f32, r.ld, r.rows, b.x, N, PMHIP_F32, M, N, K, s);
+}
+
+// LN(x) of the tower's residual stream into b.y (the unfolded path)
+int tower_layernorm(int dtype, TowerBufs& b, const float* g, const float* be, int M, int dim, hipStream_t s) {
+    if (b.hilo) return pmhip_layernorm_hilo(b.xh, b.xl, g, be, 1e-5f, b.y, dtype, M, dim, s);
+    return pmhip_layernorm(b.x, g, be, 1e-5f, b.y, dtype, M, dim, s);
+}
+
+// Folded or not must not depend on the BATCH (the two routes differ in rounding, and an image's result may not depend on
+// how many images run with it -- lanes, ranks and batch sizes all give bit-identical images): the decision looks at the
+// per-image row count and the weight shape only, and the 256x256 kernel then takes the shape whatever its tile count.
+bool fold_shape_ok(int tokens, int n_out, int dim) { return tokens % 256 == 0 && n_out % 256 == 0 && dim % 128 == 0; }
+
+// LN(x) -> head-split projection: folded when the shape is served, else LayerNorm + GEMM
 int ln_heads(int dtype, TowerBufs& b, const float* g, const float* be, const void* W, const void* Wf, const float* fc, const float* fd,
              int M, int dim, int heads, int dh, int tokens, int Np, int nparts, const int* kinds, void* const* outs, float q_scale,
              hipStream_t s) {
-    if (b.fold && b.stats_valid && Wf && pmhip_lnfold_supported(dtype, 2, M, nparts * heads * 64, dim)) {
-        const pmhip_lnfold ln{b.stats, fc, fd, 1e-5f, b.coef};
-        return pmhip_gemm_heads_ln(dtype, b.y, dim, Wf, dim, M, dim, heads, tokens, Np, nparts, kinds, outs, q_scale, &ln, s);
+    if (b.fold && Wf && fold_shape_ok(tokens, nparts * heads * 64, dim)) {
+        PM_TRY(pmhip_ln_coef(b.xh, 1e-5f, b.coef, M, dim, s));
+        const pmhip_lnfold ln{b.coef, fc, fd};
+        return pmhip_gemm_heads_ln(dtype, b.xh, dim, Wf, dim, M, dim, heads, tokens, Np, nparts, kinds, outs, q_scale, &ln, s);
     }
-    PM_TRY(pmhip_layernorm(b.x, g, be, 1e-5f, b.y, dtype, M, dim, s));
-    b.stats_valid = false;                                     // b.y now holds LN(x), not bf16(x)
+    PM_TRY(tower_layernorm(dtype, b, g, be, M, dim, s));
     return pmhip_gemm_heads_dh(dtype, b.y, dim, W, dim, M, dim, heads, dh, tokens, Np, nparts, kinds, outs, q_scale, b.split, s);
 }
 
@@ -226,7 +254,7 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
     const bool fast = dtype == PMHIP_BF16;
     const float q_scale = (dh == 64 ? 0.125f : 1.0f / sqrtf((float)dh)) * (fast ? kLog2e : 1.0f);   // dim_head^-0.5, attention.py:31,52
     const int kinds_qkv[3] = {PMHIP_PART_Q, PMHIP_PART_K, PMHIP_PART_V};
-    const float eps = 1e-5f;
+    const ResSrc self = res_self(b, dim);
 
     // x = attn1(norm1(x)) + x
     {
@@ -235,7 +263,7 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
                         q_scale, s));
     }
     PM_TRY(pmhip_attention_dh(dtype, b.q, b.k, b.vt, b.attn, inner, B, tc.heads, dh, tokens, tokens, Np, fast, s));
-    PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo, inner, L.bo, b.x, dim, M, M, dim, inner, s));
+    PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo, inner, L.bo, self, M, dim, inner, s));
 
     if (stage2) {
         // x = attn2(norm2(x), context) + x ; context None -> a second self-attention (attention.py:47)
@@ -251,19 +279,37 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
                             outs, q_scale, s));
             PM_TRY(pmhip_attention_dh(dtype, b.q, b.k, b.vt, b.attn, inner, B, tc.heads, dh, tokens, tokens, Np, fast, s));
         }
-        PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo2, inner, L.bo2, b.x, dim, M, M, dim, inner, s));
+        PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo2, inner, L.bo2, self, M, dim, inner, s));
     }
 
     // x = ffnet(norm(x)) + x
-    if (b.fold && b.stats_valid && L.w12p_f && pmhip_lnfold_supported(dtype, 1, M, 2 * tc.hidden_pad, dim)) {
-        const pmhip_lnfold ln{b.stats, L.w12_c, L.w12_d, eps, b.coef};
-        PM_TRY(pmhip_gemm_swiglu_ln(dtype, b.y, dim, L.w12p_f, L.b12p, b.hid, tc.hidden_pad, M, tc.hidden_pad, dim, &ln, s));
+    if (b.fold && L.w12p_f && fold_shape_ok(tokens, 2 * tc.hidden_pad, dim)) {
+        PM_TRY(pmhip_ln_coef(b.xh, 1e-5f, b.coef, M, dim, s));
+        const pmhip_lnfold ln{b.coef, L.w12_c, L.w12_d};
+        PM_TRY(pmhip_gemm_swiglu_ln(dtype, b.xh, dim, L.w12p_f, L.b12p, b.hid, tc.hidden_pad, M, tc.hidden_pad, dim, &ln, s));
     } else {
-        PM_TRY(pmhip_layernorm(b.x, L.ln2_g, L.ln2_b, eps, b.y, dtype, M, dim, s));
-        b.stats_valid = false;
+        PM_TRY(tower_layernorm(dtype, b, L.ln2_g, L.ln2_b, M, dim, s));
         PM_TRY(pmhip_gemm_swiglu(dtype, b.y, dim, L.w12p, L.b12p, b.hid, tc.hidden_pad, M, tc.hidden_pad, dim, s));
     }
-    return residual_gemm(dtype, b, b.hid, tc.hidden_pad, L.w3p, tc.hidden_pad, L.b3, b.x, dim, M, M, dim, tc.hidden_pad, s);
+    return residual_gemm(dtype, b, b.hid, tc.hidden_pad, L.w3p, tc.hidden_pad, L.b3, self, M, dim, tc.hidden_pad, s);
+}
+
+// a position embedding as the addend of the GEMM that opens a residual stream: the fp32 table in verify mode, its hi / lo
+// planes (split once per handle, kept in the workspace) in bf16 mode
+int pos_source(Workspace& ws, const char* tag, bool hilo, const float* pos, int rows, int dim, bool& done, ResSrc& r, hipStream_t s) {
+    r = ResSrc{};
+    r.ld = dim; r.rows = rows;
+    if (!hilo) { r.f32 = pos; return PMHIP_OK; }
+    void* hi; void* lo;
+    std::string t(tag);
+    WS(ws, (t + ".hi").c_str(), (size_t)rows * dim * 2, hi);
+    WS(ws, (t + ".lo").c_str(), (size_t)rows * dim * 2, lo);
+    if (!done) {
+        PM_TRY(pmhip_split_hilo(pos, hi, lo, rows, dim, s));
+        done = true;
+    }
+    r.hi = hi; r.lo = lo;
+    return PMHIP_OK;
 }
 
 }  // namespace
@@ -280,6 +326,7 @@ struct pmhip_vqgan {
     std::vector<pmhip_layer_weights> enc_layers, dec_layers;
     int grid = 0, tokens = 0, patch_k = 0;
     Workspace ws;
+    bool dec_pos_split = false;     // bf16 mode: the decoder position embedding has been split into hi / lo planes (ws "decpos.*")
 };
 
 extern "C" int pmhip_vqgan_create(pmhip_vqgan** out, int device, int dtype, const pmhip_vqgan_cfg* cfg,
@@ -327,7 +374,8 @@ int vq_encoder(pmhip_vqgan* h, const float* img, int B, TowerBufs& tb, hipStream
     // conv-as-GEMM (no bias) + position embedding, then norm_pre
     PM_TRY(pmhip_gemm(h->dtype, pa, h->patch_k, h->w.patch_w, h->patch_k, nullptr, h->w.enc_pos, dim, h->tokens, x0, dim,
                       PMHIP_F32, M, dim, h->patch_k, s));
-    PM_TRY(pmhip_layernorm(x0, h->w.pre_g, h->w.pre_b, 1e-5f, tb.x, PMHIP_F32, M, dim, s));
+    if (tb.hilo) PM_TRY(pmhip_layernorm_to_hilo(x0, h->w.pre_g, h->w.pre_b, 1e-5f, tb.xh, tb.xl, M, dim, s));
+    else PM_TRY(pmhip_layernorm(x0, h->w.pre_g, h->w.pre_b, 1e-5f, tb.x, PMHIP_F32, M, dim, s));
     for (int l = 0; l < c.enc.depth; ++l)
         PM_TRY(layer_forward(h->dtype, h->enc_layers[l], c.enc, tb, B, h->tokens, false, nullptr, s));
     return PMHIP_OK;
@@ -342,7 +390,7 @@ int vq_decoder_tower(pmhip_vqgan* h, TowerBufs& tb, int B, float* img_out, bool 
         PM_TRY(layer_forward(h->dtype, h->dec_layers[l], c.dec, tb, B, h->tokens, false, nullptr, s));
     float* yo;
     WS(h->ws, "dec.pixels", (size_t)M * h->patch_k * 4, yo);
-    PM_TRY(pmhip_layernorm(tb.x, h->w.dn_g, h->w.dn_b, 1e-5f, tb.y, h->dtype, M, dim, s));
+    PM_TRY(tower_layernorm(h->dtype, tb, h->w.dn_g, h->w.dn_b, M, dim, s));
     PM_TRY(pmhip_gemm(h->dtype, tb.y, dim, h->w.proj_w, dim, h->w.proj_b, nullptr, 0, 0, yo, h->patch_k, PMHIP_F32, M,
                       h->patch_k, dim, s));
     const float lim = clamp ? 1.0f : INFINITY;
@@ -356,7 +404,9 @@ int vq_decode_latent(pmhip_vqgan* h, const void* zp, int B, float* img_out, hipS
     TowerBufs tb;
     PM_TRY(alloc_tower(h->ws, "dec", h->dtype, c.dec, B, h->tokens, tb, s));
     // post_quant + position embedding fused (vqmodel.py:28, layers.py:146)
-    PM_TRY(residual_gemm(h->dtype, tb, zp, 64, h->w.postq_w, 64, h->w.postq_b, h->w.dec_pos, dim, h->tokens, M, dim, 64, s));
+    ResSrc pos;
+    PM_TRY(pos_source(h->ws, "decpos", tb.hilo, h->w.dec_pos, h->tokens, dim, h->dec_pos_split, pos, s));
+    PM_TRY(residual_gemm(h->dtype, tb, zp, 64, h->w.postq_w, 64, h->w.postq_b, pos, M, dim, 64, s));
     return vq_decoder_tower(h, tb, B, img_out, true, s);
 }
 
@@ -376,6 +426,7 @@ extern "C" int pmhip_vqgan_encoder_forward(pmhip_vqgan* h, const float* img, int
     hipStream_t s = (hipStream_t)stream;
     TowerBufs tb;
     PM_TRY(vq_encoder(h, img, B, tb, s));
+    if (tb.hilo) return pmhip_join_hilo(tb.xh, tb.xl, x_out, B * h->tokens, h->cfg.enc.dim, s);
     PM_HIP(hipMemcpyAsync(x_out, tb.x, (size_t)B * h->tokens * h->cfg.enc.dim * 4, hipMemcpyDeviceToDevice, s));
     return PMHIP_OK;
 }
@@ -388,12 +439,8 @@ extern "C" int pmhip_vqgan_encode(pmhip_vqgan* h, const float* img, int B, float
     const int M = B * h->tokens, dim = c.enc.dim, E = c.embed_dim;
     TowerBufs tb;
     PM_TRY(vq_encoder(h, img, B, tb, s));
-    // prev_quant acts on the raw residual stream (vqmodel.py:23): cast it to T when T != f32
-    const void* xin = tb.x;
-    if (h->dtype != PMHIP_F32) {
-        PM_TRY(pmhip_convert_pad(tb.x, dim, tb.y, h->dtype, dim, M, s));
-        xin = tb.y;
-    }
+    // prev_quant acts on the raw residual stream (vqmodel.py:23): in bf16 mode its operand bf16(x) is the hi plane
+    const void* xin = tb.hilo ? tb.xh : (const void*)tb.x;
     float* ze; void* scratch;
     WS(h->ws, "enc.ze", (size_t)M * E * 4, ze);
     WS(h->ws, "enc.vq", pmhip_vq_scratch_bytes(M, c.n_embed), scratch);
@@ -424,7 +471,14 @@ extern "C" int pmhip_vqgan_decoder_forward(pmhip_vqgan* h, const float* x, int B
     const int M = B * h->tokens;
     TowerBufs tb;
     PM_TRY(alloc_tower(h->ws, "dec", h->dtype, h->cfg.dec, B, h->tokens, tb, s));
-    PM_TRY(pmhip_add_rows(x, h->w.dec_pos, h->tokens, tb.x, M, h->cfg.dec.dim, s));
+    if (tb.hilo) {
+        float* x0;
+        WS(h->ws, "dec.x0", (size_t)M * h->cfg.dec.dim * 4, x0);
+        PM_TRY(pmhip_add_rows(x, h->w.dec_pos, h->tokens, x0, M, h->cfg.dec.dim, s));
+        PM_TRY(pmhip_split_hilo(x0, tb.xh, tb.xl, M, h->cfg.dec.dim, s));
+    } else {
+        PM_TRY(pmhip_add_rows(x, h->w.dec_pos, h->tokens, tb.x, M, h->cfg.dec.dim, s));
+    }
     return vq_decoder_tower(h, tb, B, img_out, false, s);
 }
 
@@ -449,6 +503,7 @@ struct pmhip_s2 {
     std::vector<pmhip_layer_weights> layers;
     std::vector<CrossKV> cross;     // per layer, valid after prepare_context
     Workspace ws;
+    bool pos_split = false;         // bf16 mode: position embedding split into hi / lo planes (ws "pos.*")
     std::map<std::string, GraphEntry> graphs;   // captured decode loops, keyed by shape / schedule structure
     hipStream_t capture_stream = nullptr;       // capture never happens on the caller's stream (it may be the NULL stream)
     // per-call scalars travel through PINNED host slots (a pageable source makes hipMemcpyAsync stage synchronously);
@@ -543,15 +598,18 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s) {
     const int M = B * c.tokens, dim = c.tower.dim;
     TowerBufs tb;
     PM_TRY(alloc_tower(h->ws, "s2", h->dtype, c.tower, B, c.tokens, tb, s));
-    PM_TRY(residual_gemm(h->dtype, tb, tp, 64, h->w.tokproj_w, 64, h->w.tokproj_b, h->w.pos, dim, c.tokens, M, dim, 64, s));
+    ResSrc pos;
+    PM_TRY(pos_source(h->ws, "pos", tb.hilo, h->w.pos, c.tokens, dim, h->pos_split, pos, s));
+    PM_TRY(residual_gemm(h->dtype, tb, tp, 64, h->w.tokproj_w, 64, h->w.tokproj_b, pos, M, dim, 64, s));
     for (int l = 0; l < c.tower.depth; ++l)
         PM_TRY(layer_forward(h->dtype, h->layers[l], c.tower, tb, B, c.tokens, true, &h->cross[l], s));
-    if (tb.fold && tb.stats_valid && h->w.logits_wf && pmhip_lnfold_supported(h->dtype, 0, M, c.n_embed, dim)) {
-        const pmhip_lnfold ln{tb.stats, h->w.logits_c, h->w.logits_d, 1e-5f, tb.coef};      // the final norm folded into to_logits
-        return pmhip_gemm_ln(h->dtype, tb.y, dim, h->w.logits_wf, dim, h->w.logits_b, logits, c.n_embed, PMHIP_F32, M, c.n_embed, dim,
+    if (tb.fold && h->w.logits_wf && fold_shape_ok(c.tokens, c.n_embed, dim)) {
+        PM_TRY(pmhip_ln_coef(tb.xh, 1e-5f, tb.coef, M, dim, s));
+        const pmhip_lnfold ln{tb.coef, h->w.logits_c, h->w.logits_d};                    // the final norm folded into to_logits
+        return pmhip_gemm_ln(h->dtype, tb.xh, dim, h->w.logits_wf, dim, h->w.logits_b, logits, c.n_embed, PMHIP_F32, M, c.n_embed, dim,
                              &ln, s);
     }
-    PM_TRY(pmhip_layernorm(tb.x, h->w.norm_g, h->w.norm_b, 1e-5f, tb.y, h->dtype, M, dim, s));
+    PM_TRY(tower_layernorm(h->dtype, tb, h->w.norm_g, h->w.norm_b, M, dim, s));
     return pmhip_gemm(h->dtype, tb.y, dim, h->w.logits_w, dim, h->w.logits_b, nullptr, 0, 0, logits, c.n_embed, PMHIP_F32, M,
                       c.n_embed, dim, s);
 }

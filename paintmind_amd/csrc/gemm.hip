@@ -126,8 +126,8 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
     // the LDS stage that is idle after the K loop (stage nk&1: its last reads finished before the final barrier)
     // is the epilogue's transposition buffer
     unsigned char* eraw = lds + (nk & 1) * STAGE_BYTES + wave * EPI_WAVE_BYTES;
-    if constexpr (RPRE) {
-        if (p.xb_out) { wave_epilogue<EPI, OutT, 4, 16, false, -1, true>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre); return; }
+    if constexpr (EPI == EPI_STD && sizeof(OutT) == 2 && sizeof(T) == 2) {
+        if (p.out_lo) { wave_epilogue<EPI, OutT, 4, 1, false, 2>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre); return; }   // bf16 hi/lo residual stream
     }
     wave_epilogue<EPI, OutT, 4>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre);
 }
@@ -182,17 +182,20 @@ namespace {
 // LayerNorm fold (gemm_common.h): checks shared by the three consumer entry points; fills the consumer fields
 int set_lnfold(GemmParams& p, const pmhip_lnfold* ln, int dtype, int epi, int out_dtype) {
     if (!ln) return PMHIP_OK;
-    PM_REQUIRE(ln->stats && ln->c && ln->d && ln->coef, "gemm_ln: null fold pointer");
+    PM_REQUIRE(ln->coef && ln->c && ln->d, "gemm_ln: null fold pointer");
     PM_REQUIRE(dtype == PMHIP_BF16, "gemm_ln: the LayerNorm fold exists in bf16 mode only");
     PM_REQUIRE(p.K % 128 == 0, "gemm_ln: K=%d must be a multiple of 128", p.K);
-    p.ln_stats = ln->stats; p.ln_c = ln->c; p.ln_d = ln->d; p.ln_eps = ln->eps; p.ln_nc = p.K / 64; p.ln_coef = ln->coef;
-    PM_REQUIRE(pm_gemm256_supported(p, dtype, epi, out_dtype), "gemm_ln: shape M=%d N=%d K=%d is not served by the 256x256 kernel", p.M, p.N, p.K);
+    p.ln_c = ln->c; p.ln_d = ln->d; p.ln_coef = ln->coef;
+    // any tile count: whether a LayerNorm is folded must not depend on the batch size (see pmhip_lnfold_supported)
+    PM_REQUIRE(p.M % 256 == 0 && p.N % 256 == 0 && (unsigned long long)p.M * p.lda * 2 < (1ull << 31) &&
+               (unsigned long long)p.N * p.ldw * 2 < (1ull << 31),
+               "gemm_ln: shape M=%d N=%d K=%d is not served by the 256x256 kernel (M, N multiples of 256)", p.M, p.N, p.K);
     return PMHIP_OK;
 }
 
 int gemm_impl(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
                           const float* residual, int ldr, int res_rows, void* out, int ldo, int out_dtype,
-                          int M, int N, int K, void* xb_out, int ldxb, float* stats_out, const pmhip_lnfold* ln, pmhip_stream stream) {
+                          int M, int N, int K, const pmhip_lnfold* ln, pmhip_stream stream) {
     GemmParams p{};
     p.A = A; p.W = W; p.bias = bias; p.residual = residual; p.out = out;
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.res_rows = res_rows > 0 ? res_rows : M; p.ldo = ldo;
@@ -204,22 +207,11 @@ int gemm_impl(int dtype, const void* A, int lda, const void* W, int ldw, const f
     PM_REQUIRE(!residual || out_dtype == PMHIP_F32, "gemm: a residual needs an f32 output (the residual stream is f32)");
     PM_REQUIRE(out_dtype == PMHIP_F32 || out_dtype == dtype, "gemm: out dtype must be f32 or the compute dtype");
     PM_REQUIRE(out_dtype == PMHIP_F32 || ldo % 8 == 0, "gemm: bf16 output needs ldo to be a multiple of 8");
-    if (xb_out || stats_out) {
-        PM_REQUIRE(xb_out && stats_out && out_dtype == PMHIP_F32 && N % 64 == 0 && ldxb % 4 == 0,
-                   "gemm_stats: needs both outputs, an f32 result and N a multiple of 64");
-        p.xb_out = reinterpret_cast<bf16_t*>(xb_out); p.ldxb = ldxb; p.stats_out = stats_out;
-    }
     PM_TRY(set_lnfold(p, ln, dtype, EPI_STD, out_dtype));
     hipStream_t s = (hipStream_t)stream;
-    if (ln) {
-        PM_TRY(pm_ln_finalize(p.ln_stats, p.ln_nc, p.M, p.ln_eps, ln->coef, stream));
-        return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
-    }
-    // the large-tile kernels emit the bf16 copy + row statistics only from their residual epilogue; without a residual the
-    // 128x128 kernel serves the request (it handles every combination)
-    const bool big_ok = !(p.xb_out && !p.residual);
-    if (big_ok && use2b(p, dtype, EPI_STD, out_dtype)) return pm_gemm2b_launch(p, EPI_STD, out_dtype, s);
-    if (big_ok && use256(p, dtype, EPI_STD, out_dtype)) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
+    if (ln) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
+    if (use2b(p, dtype, EPI_STD, out_dtype)) return pm_gemm2b_launch(p, EPI_STD, out_dtype, s);
+    if (use256(p, dtype, EPI_STD, out_dtype)) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_STD, float>(p, s);
     if (out_dtype == PMHIP_F32) return launch<bf16_t, EPI_STD, float>(p, s);
     return launch<bf16_t, EPI_STD, bf16_t>(p, s);
@@ -230,26 +222,36 @@ int gemm_impl(int dtype, const void* A, int lda, const void* W, int ldw, const f
 extern "C" int pmhip_gemm(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
                           const float* residual, int ldr, int res_rows, void* out, int ldo, int out_dtype,
                           int M, int N, int K, pmhip_stream stream) {
-    return gemm_impl(dtype, A, lda, W, ldw, bias, residual, ldr, res_rows, out, ldo, out_dtype, M, N, K, nullptr, 0, nullptr, nullptr, stream);
+    return gemm_impl(dtype, A, lda, W, ldw, bias, residual, ldr, res_rows, out, ldo, out_dtype, M, N, K, nullptr, stream);
 }
 
-extern "C" int pmhip_gemm_stats(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
-                                const float* residual, int ldr, int res_rows, float* out, int ldo, void* xb_out, int ldxb,
-                                float* stats_out, int M, int N, int K, pmhip_stream stream) {
-    PM_REQUIRE(xb_out && stats_out, "gemm_stats: null output");
-    return gemm_impl(dtype, A, lda, W, ldw, bias, residual, ldr, res_rows, out, ldo, PMHIP_F32, M, N, K, xb_out, ldxb, stats_out, nullptr, stream);
+// bf16 hi/lo residual stream: (hi, lo) <- split(A . W^T + bias + (res_hi + res_lo)); in place when the planes coincide
+extern "C" int pmhip_gemm_hilo(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
+                               const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N, int K,
+                               pmhip_stream stream) {
+    GemmParams p{};
+    p.A = A; p.W = W; p.bias = bias; p.residual = reinterpret_cast<const float*>(res_hi); p.out = out_hi;
+    p.res_lo = reinterpret_cast<const bf16_t*>(res_lo); p.out_lo = reinterpret_cast<bf16_t*>(out_lo);
+    p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.res_rows = res_rows > 0 ? res_rows : M; p.ldo = ldo;
+    p.M = M; p.N = N; p.K = K;
+    PM_TRY(check_common(p, PMHIP_BF16));
+    PM_REQUIRE(res_hi && res_lo && out_hi && out_lo, "gemm_hilo: null plane");
+    PM_REQUIRE(N % 8 == 0 && ldo % 8 == 0 && ldr % 8 == 0, "gemm_hilo: N=%d, ldo=%d, ldr=%d must be multiples of 8", N, ldo, ldr);
+    hipStream_t s = (hipStream_t)stream;
+    if (use2b(p, PMHIP_BF16, EPI_STD, PMHIP_BF16)) return pm_gemm2b_launch(p, EPI_STD, PMHIP_BF16, s);
+    if (use256(p, PMHIP_BF16, EPI_STD, PMHIP_BF16)) return pm_gemm256_launch(p, EPI_STD, PMHIP_BF16, s);
+    return launch<bf16_t, EPI_STD, bf16_t>(p, s);
 }
 
 extern "C" int pmhip_gemm_ln(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldo,
                              int out_dtype, int M, int N, int K, const pmhip_lnfold* ln, pmhip_stream stream) {
     PM_REQUIRE(ln, "gemm_ln: null fold descriptor");
-    return gemm_impl(dtype, A, lda, W, ldw, bias, nullptr, 0, 0, out, ldo, out_dtype, M, N, K, nullptr, 0, nullptr, ln, stream);
+    return gemm_impl(dtype, A, lda, W, ldw, bias, nullptr, 0, 0, out, ldo, out_dtype, M, N, K, ln, stream);
 }
 
 extern "C" int pmhip_lnfold_supported(int dtype, int epi_kind, int M, int N, int K) {
-    GemmParams p{};
-    p.M = M; p.N = N; p.K = K;
-    return dtype == PMHIP_BF16 && K % 128 == 0 && epi_kind >= 0 && epi_kind <= 2 && pm_gemm256_supported(p, dtype, epi_kind, dtype) ? 1 : 0;
+    return dtype == PMHIP_BF16 && K % 128 == 0 && K >= 128 && epi_kind >= 0 && epi_kind <= 2 && M % 256 == 0 && N % 256 == 0 &&
+           (unsigned long long)M * K * 2 < (1ull << 31) && (unsigned long long)N * K * 2 < (1ull << 31) ? 1 : 0;
 }
 
 static int gemm_swiglu_impl(int dtype, const void* A, int lda, const void* W12p, const float* b12p,
@@ -263,10 +265,7 @@ static int gemm_swiglu_impl(int dtype, const void* A, int lda, const void* W12p,
     PM_REQUIRE(b12p && out && ldo % 8 == 0, "gemm_swiglu: bias/out required, ldo multiple of 8");
     PM_TRY(set_lnfold(p, ln, dtype, EPI_SWIGLU, dtype));
     hipStream_t s = (hipStream_t)stream;
-    if (ln) {
-        PM_TRY(pm_ln_finalize(p.ln_stats, p.ln_nc, p.M, p.ln_eps, ln->coef, stream));
-        return pm_gemm256_launch(p, EPI_SWIGLU, dtype, s);
-    }
+    if (ln) return pm_gemm256_launch(p, EPI_SWIGLU, dtype, s);
     if (use2b(p, dtype, EPI_SWIGLU, dtype)) return pm_gemm2b_launch(p, EPI_SWIGLU, dtype, s);
     if (use256(p, dtype, EPI_SWIGLU, dtype)) return pm_gemm256_launch(p, EPI_SWIGLU, dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_SWIGLU, float>(p, s);
@@ -304,10 +303,7 @@ static int gemm_heads_impl(int dtype, const void* A, int lda, const void* W, int
     PM_TRY(check_common(p, dtype));
     PM_TRY(set_lnfold(p, ln, dtype, EPI_HEADS, dtype));
     hipStream_t s = (hipStream_t)stream;
-    if (ln) {
-        PM_TRY(pm_ln_finalize(p.ln_stats, p.ln_nc, p.M, p.ln_eps, ln->coef, stream));
-        return pm_gemm256_launch(p, EPI_HEADS, dtype, s);
-    }
+    if (ln) return pm_gemm256_launch(p, EPI_HEADS, dtype, s);
     if (use2b(p, dtype, EPI_HEADS, dtype)) return pm_gemm2b_launch(p, EPI_HEADS, dtype, s);
     if (use256(p, dtype, EPI_HEADS, dtype)) return pm_gemm256_launch(p, EPI_HEADS, dtype, s);
     if (dtype == PMHIP_F32) return launch<float, EPI_HEADS, float>(p, s);

@@ -136,9 +136,10 @@ enum { KT_STEADY = 0, KT_FIRST = 1, KT_LAST = 2 };
 // ({MFMAs of the previous phase | reads}).  Both roles execute the SAME sequence of barriers, DMA issues and vmcnt waits.
 template <bool LEAD, int KIND, bool FOLD>
 __device__ __forceinline__ void k_tile(const GemmParams& p, const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], uint4 (&a)[4][2],
-                                       uint4 (&w)[2][2], LnCoef& lnc, int kt, int pb) {
-    // LayerNorm fold: the tile's per-row coefficients are loaded in the first read slot of its LAST K-tile (LN_COEF_LOADS more
-    // operations in flight through phases 1 and 2, older than the phase's DMA) and are retired by the closing vmcnt(0)
+                                       uint4 (&w)[2][2], float* fscr, int kt, int pb) {
+    // LayerNorm fold: the tile's per-row coefficients are DMA'd into the wave's scratch in the first read slot of its LAST
+    // K-tile (LN_COEF_LOADS more operations in flight through phases 1 and 2, older than the phase's DMA) and are retired by
+    // the closing vmcnt(0)
     constexpr int XL = (FOLD && KIND == KT_LAST) ? LN_COEF_LOADS : 0;
     constexpr bool FIRST = KIND == KT_FIRST;
     constexpr bool ONE_PER_PHASE = KIND != KT_LAST;
@@ -153,7 +154,7 @@ __device__ __forceinline__ void k_tile(const GemmParams& p, const LoopCtx& c, un
         if constexpr (phase == 1) { ISSUE(PA0) } else if constexpr (phase == 2) { ISSUE(PW0) }                       \
         else if constexpr (phase == 3) { ISSUE(PW1) } else { ISSUE(PA1) }                                            \
     } else {                                                                                                         \
-        if constexpr (phase == 1 && FOLD) ln_coef_issue(p, c.mw, c.nw, c.lane, lnc);                                 \
+        if constexpr (phase == 1 && FOLD) ln_coef_issue(p, c.mw, c.nw, c.lane, fscr);                                 \
         if constexpr (phase == 1) { ISSUE_NEXT_TILE(PA0) ISSUE_NEXT_TILE(PW0) }                                      \
         else if constexpr (phase == 2) { ISSUE_NEXT_TILE(PW1) ISSUE_NEXT_TILE(PA1) }                                 \
     }
@@ -163,7 +164,7 @@ __device__ __forceinline__ void k_tile(const GemmParams& p, const LoopCtx& c, un
     else if constexpr (XL == 0) {                                                                                    \
         if constexpr (phase == 1) VMW(6) else if constexpr (phase == 2) VMW(8) else if constexpr (phase == 4) VMW(0) \
     } else {                                                                                                         \
-        if constexpr (phase == 1) VMW(15) else if constexpr (phase == 2) VMW(17) else if constexpr (phase == 4) VMW(0) \
+        if constexpr (phase == 1) VMW(9) else if constexpr (phase == 2) VMW(11) else if constexpr (phase == 4) VMW(0) \
     }
     // ---------------- phase 1: A rows [0,64) x W rows [0,32)
     // KT_LAST: its phase-1 DMA writes W rows [0,32) of the OTHER buffer, which the lag waves read (RD_W(0), phase 4 of the
@@ -202,11 +203,11 @@ __device__ __forceinline__ void k_tile(const GemmParams& p, const LoopCtx& c, un
 
 // The K loop of one output tile for one wave: straight-line K-tiles, the first and the last peeled (nk >= 2).
 template <bool LEAD, bool FOLD>
-__device__ __forceinline__ void k_loop(const GemmParams& p, const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], LnCoef& lnc, int pb) {
+__device__ __forceinline__ void k_loop(const GemmParams& p, const LoopCtx& c, unsigned char* lds, f32x4_t (&acc)[8][4], float* fscr, int pb) {
     uint4 a[4][2], w[2][2];                        // [fragment][kk]
-    k_tile<LEAD, KT_FIRST, FOLD>(p, c, lds, acc, a, w, lnc, 0, pb);
-    for (int kt = 1; kt + 1 < c.nk; ++kt) k_tile<LEAD, KT_STEADY, FOLD>(p, c, lds, acc, a, w, lnc, kt, pb);
-    k_tile<LEAD, KT_LAST, FOLD>(p, c, lds, acc, a, w, lnc, c.nk - 1, pb);
+    k_tile<LEAD, KT_FIRST, FOLD>(p, c, lds, acc, a, w, fscr, 0, pb);
+    for (int kt = 1; kt + 1 < c.nk; ++kt) k_tile<LEAD, KT_STEADY, FOLD>(p, c, lds, acc, a, w, fscr, kt, pb);
+    k_tile<LEAD, KT_LAST, FOLD>(p, c, lds, acc, a, w, fscr, c.nk - 1, pb);
     if constexpr (!LEAD) { LGKM0; MMA(1, 0) }
 }
 #undef DSR
@@ -288,25 +289,22 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
         c.aorg1 = (unsigned)m1 * c.lda_b; c.worg1 = (unsigned)n1 * c.ldw_b;
 
         c.mw = m0 + wm * 128; c.nw = n0 + wn * 64;
-        LnCoef lnc;
-        if (wm == 0) k_loop<true, FOLD>(p, c, lds, acc, lnc, pb); else k_loop<false, FOLD>(p, c, lds, acc, lnc, pb);
+        if (wm == 0) k_loop<true, FOLD>(p, c, lds, acc, fscr, pb); else k_loop<false, FOLD>(p, c, lds, acc, fscr, pb);
 
         // every fragment read finished before the last barrier.  The buffer of the LAST K-tile is free for the epilogue's
         // staging (8 KiB per wave); the other one already holds the next tile's first K-tile.
-        if constexpr (FOLD) {
-            float fa[8], fb[8];
-            ln_coef_finish(lane, fscr, lnc, fa, fb);
-            ln_apply<8>(fscr, acc, lane, fa, fb);
-        }
+        if constexpr (FOLD) ln_apply<8>(fscr, acc, lane);          // the coefficient DMA was retired by the last K-tile's vmcnt(0)
         const float4 no_pre[1] = {};
         unsigned char* eraw = lds + ((pb + c.nk - 1) & 1) * BUF_BYTES + wave * EPI_WAVE_BYTES;
         const int mw = m0 + wm * 128, nw = n0 + wn * 64;
         if constexpr (EPI == EPI_STD && sizeof(OutT) == 4) {
-            if (p.residual && p.xb_out) wave_epilogue<EPI, OutT, 8, 1, true, 1, true>(p, acc, eraw, mw, nw, lane, no_pre);
-            else if (p.residual) wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, mw, nw, lane, no_pre);
-            else wave_epilogue<EPI, OutT, 8, 1, true, 0, false>(p, acc, eraw, mw, nw, lane, no_pre);
+            if (p.residual) wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, mw, nw, lane, no_pre);
+            else wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, mw, nw, lane, no_pre);
+        } else if constexpr (EPI == EPI_STD) {
+            if (p.out_lo) wave_epilogue<EPI, OutT, 8, 1, true, 2>(p, acc, eraw, mw, nw, lane, no_pre);      // bf16 hi/lo residual stream
+            else wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, mw, nw, lane, no_pre);
         } else {
-            wave_epilogue<EPI, OutT, 8, 1, true, 0, false>(p, acc, eraw, mw, nw, lane, no_pre);
+            wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, mw, nw, lane, no_pre);
         }
         if (!has_next) break;
         __builtin_amdgcn_s_barrier();                  // every wave is done staging through the free buffer (the next K-tile 1 lands there)

@@ -130,8 +130,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm2b_kernel(const GemmParams p) 
     const float4 no_pre[1] = {};
     unsigned char* eraw = lds + wave * EPI_WAVE_BYTES;
     if constexpr (EPI == EPI_STD && sizeof(OutT) == 4) {
-        if (p.residual && p.xb_out) wave_epilogue<EPI, OutT, 8, 1, true, 1, true>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
-        else if (p.residual) wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
+        if (p.residual) wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
+        else wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
+    } else if constexpr (EPI == EPI_STD) {
+        if (p.out_lo) wave_epilogue<EPI, OutT, 8, 1, true, 2>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);   // bf16 hi/lo residual stream
         else wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);
     } else {
         wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, m0 + wm * 128, n0 + wn * 64, lane, no_pre);

@@ -24,16 +24,15 @@ struct GemmParams {
     float q_scale;
     int fast_math;                                 // SwiGLU: 1 = fast exp (bf16 mode)
     int chunk;                                     // n-tiles per L2 chunk of the tile walk (256x256 kernel)
-    // LayerNorm fold, producer side (EPI_STD, f32 out): also write the row as bf16 and, per 64-column chunk,
-    // (sum x, sum x^2) of the row -> stats_out[N/64][m][2] (chunk-major)
-    bf16_t* xb_out; int ldxb;
-    float* stats_out;
-    // LayerNorm fold, consumer side (256x256 kernel): A is the RAW bf16 row, W carries gamma, and the epilogue applies
-    // out = rstd * acc - rstd * mean * c[n] + d[n] with (mean, rstd) from the producer's partial sums
-    const float* ln_stats; int ln_nc;              // [ln_nc][M][2], ln_nc = K / 64
-    const float* ln_coef;                          // [M][2]: (rstd, -rstd * mean), reduced from ln_stats by pm_ln_finalize
+    // bf16 hi/lo residual stream (EPI_STD, bf16 out, RES == 2): x = hi + lo, two bf16 planes.  `residual` then points at
+    // the hi plane (bf16, row stride ldr), res_lo at the lo plane; `out` is the new hi plane, out_lo the new lo plane (row
+    // stride ldo).  The hi plane alone is what the next GEMM consumes (LayerNorm folded into it), so the stream costs the
+    // same 4 + 4 bytes per element as fp32 but needs no separate normalisation pass.
+    const bf16_t* res_lo; bf16_t* out_lo;
+    // LayerNorm fold, consumer side (256x256 kernel): A is the RAW bf16 row (the hi plane), W carries gamma, and the epilogue
+    // applies out = rstd * acc - rstd * mean * c[n] + d[n]
+    const float* ln_coef;                          // [M][2]: (rstd, -rstd * mean) per row, from pmhip_ln_coef
     const float* ln_c; const float* ln_d;          // [N]: c = sum_k bf16(gamma_k W_nk), d = sum_k beta_k W_nk
-    float ln_eps;
 };
 
 // XCD-aware, bijective block remap: consecutive virtual ids stay on one XCD's L2 (block b runs on XCD b % 8).
@@ -71,103 +70,45 @@ __device__ __forceinline__ float silu_mul(float x1, float x2, int fast) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm fold, consumer side.  ln_row_coeffs: (rstd, -rstd * mean) of the MI rows this lane owns in the
-// accumulator layout (row mwave + mi*16 + l15), from the producer's per-64-column partial sums.  Deterministic: the
-// partials are summed in chunk order.  ln_apply: acc = rstd * acc - rstd * mean * c[n] + d[n].
+// LayerNorm fold, consumer side.  ln_coef_issue / ln_coef_finish: (rstd, -rstd * mean) of the MI rows this lane owns in the
+// accumulator layout (row mwave + mi*16 + l15).  ln_apply: acc = rstd * acc - rstd * mean * c[n] + d[n].
 // ------------------------------------------------------------------------------------------------
-// Statistics layout: stats[chunk][row][2] (chunk-major), so that for one chunk the 128 rows of a wave are 1 KiB of
-// contiguous memory: lane j fetches rows 2j and 2j+1 of every chunk with ONE coalesced 16-byte load per chunk, all
-// issued before the first is consumed (one memory round trip).  The (rstd, -rstd*mean) pairs then go through `scratch`
-// (LDS private to the wave) so that each lane picks up the 8 rows it owns in the accumulator layout; the wave's 64
-// entries of c and d ride along into scratch[256 .. 383] so the epilogue reads them from LDS.
-// The loads are inline asm: hipcc would otherwise wait vmcnt(0) -- draining the LDS-DMA of the first K-tile that is in
-// flight at the same time -- before their first use.  ln_stats_issue goes BEFORE the DMA pieces are issued,
-// ln_row_coeffs after them with `dma_in_flight` = the number of DMA instructions issued in between (counted wait).
-// Round 2, second version: the consumer reads the per-row pair (rstd, -rstd * mean) that pm_ln_finalize reduced from the
-// partial sums -- 8 eight-byte loads per lane plus one for c | d, issued (inline asm, invisible to hipcc's waits) in the
+// The consumer reads the per-row pair (rstd, -rstd * mean) that pmhip_ln_coef computed from the hi plane -- 8 eight-byte
+// loads per lane plus one for c | d, issued (inline asm, invisible to hipcc's waits) in the
 // first read slot of the tile's LAST K-tile and retired by that K-tile's closing vmcnt(0), so the fold costs the persistent,
 // streamed K loop nothing but 20 registers in its last K-tile.
-struct LnCoef { float2 ab[8]; f32x4_t cd; };
-__device__ __forceinline__ void ln_coef_issue(const GemmParams& p, int mwave, int nw, int lane, LnCoef& L) {
-    const float* a = p.ln_coef + ((size_t)mwave + (lane & 15)) * 2;
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(L.ab[mi]) : "v"(a + mi * 32) : "memory");
-    const float* cda = (lane < 16 ? p.ln_c : p.ln_d) + nw + (lane & 15) * 4;      // lanes >= 32 re-read lanes 0-31's addresses
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(L.cd) : "v"(cda) : "memory");
-}
-constexpr int LN_COEF_LOADS = 9;
-// after the loads have been waited for: c | d go through the wave's LDS scratch (ln_apply reads them from there)
-__device__ __forceinline__ void ln_coef_finish(int lane, float* scratch, LnCoef& L, float (&fa)[8], float (&fb)[8]) {
-    if (lane < 32) *reinterpret_cast<f32x4_t*>(scratch + 256 + lane * 4) = L.cd;
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) { fa[mi] = L.ab[mi].x; fb[mi] = L.ab[mi].y; }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-constexpr int LN_MAXC = 16;
-struct LnLoads { f32x4_t t[LN_MAXC]; f32x4_t cd; };
-
-__device__ __forceinline__ void ln_stats_issue(const GemmParams& p, int mwave, int nw, int lane, LnLoads& L) {
-    const float* st = p.ln_stats + ((size_t)mwave + 2 * lane) * 2;
-    const size_t cstride = (size_t)p.M * 2;
-#pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-        if (c < p.ln_nc) {                                          // wave-uniform (scalar branch): no per-lane predication
-            const float* a = st + c * cstride;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(L.t[c]) : "v"(a) : "memory");
-        }
-    }
-    const float* cda = (lane < 16 ? p.ln_c : p.ln_d) + nw + (lane & 15) * 4;      // lanes >= 32 re-read lanes 0-31's addresses
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(L.cd) : "v"(cda) : "memory");
-}
-
-template <int DMA_IN_FLIGHT>
-__device__ __forceinline__ void ln_row_coeffs(const GemmParams& p, int lane, float* scratch, LnLoads& L, float (&fa)[8], float (&fb)[8]) {
-    const int l15 = lane & 15;
-    // every statistics load is older than the DMA instructions: leave exactly those in flight
-    asm volatile("s_waitcnt vmcnt(%17)"
-                 : "+v"(L.t[0]), "+v"(L.t[1]), "+v"(L.t[2]), "+v"(L.t[3]), "+v"(L.t[4]), "+v"(L.t[5]), "+v"(L.t[6]), "+v"(L.t[7]),
-                   "+v"(L.t[8]), "+v"(L.t[9]), "+v"(L.t[10]), "+v"(L.t[11]), "+v"(L.t[12]), "+v"(L.t[13]), "+v"(L.t[14]), "+v"(L.t[15]),
-                   "+v"(L.cd)
-                 : "n"(DMA_IN_FLIGHT) : "memory");
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c)
-        if (c < p.ln_nc) { s[0] += L.t[c][0]; s[1] += L.t[c][1]; s[2] += L.t[c][2]; s[3] += L.t[c][3]; }      // chunk order: deterministic
-    const float invD = 1.0f / (float)(p.ln_nc * 64);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const float mean = s[2 * r] * invD;
-        const float var = fmaxf(s[2 * r + 1] * invD - mean * mean, 0.f);
-        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
-        *reinterpret_cast<float2*>(scratch + (2 * lane + r) * 2) = make_float2(rstd, -rstd * mean);
-    }
-    if (lane < 32) *reinterpret_cast<f32x4_t*>(scratch + 256 + lane * 4) = L.cd;
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const float2 ab = *reinterpret_cast<const float2*>(scratch + (mi * 16 + l15) * 2);
-        fa[mi] = ab.x;
-        fb[mi] = ab.y;
-    }
+// The coefficients travel by LDS-DMA into the wave's private scratch -- no register is held across the K loop (held in
+// registers, 20 of them, the head-split variant spilled in its last K-tile: 154 vs 124 us):
+//   scratch[0 .. 255]    (rstd, -rstd * mean) of the wave's 128 rows: 1 KiB contiguous in coef[M][2], ONE 16-byte DMA
+//   scratch[256 .. 319]  c[nw .. nw+63],  scratch[320 .. 383]  d[nw .. nw+63]: one 4-byte DMA each
+// issued in the first read slot of the tile's LAST K-tile and retired by that K-tile's closing vmcnt(0).
+constexpr int LN_COEF_LOADS = 3;
+__device__ __forceinline__ void ln_coef_issue(const GemmParams& p, int mwave, int nw, int lane, float* scratch) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    __builtin_amdgcn_global_load_lds((gbl_void*)(p.ln_coef + (size_t)mwave * 2 + lane * 4), (lds_void*)scratch, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(p.ln_c + nw + lane), (lds_void*)(scratch + 256), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(p.ln_d + nw + lane), (lds_void*)(scratch + 320), 4, 0, 0);
 }
 
 template <int MI>
-__device__ __forceinline__ void ln_apply(const float* scratch, f32x4_t (&acc)[MI][4], int lane, const float (&fa)[MI],
-                                         const float (&fb)[MI]) {
-    const int g = lane >> 4;
+__device__ __forceinline__ void ln_apply(const float* scratch, f32x4_t (&acc)[MI][4], int lane) {
+    const int g = lane >> 4, l15 = lane & 15;
+    float4 cc[4], dd[4];                                           // c | d of the lane's 4 x 4 columns
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {                               // c | d of one 16-column group at a time: 8 live registers, not 32
-        const float4 cc = *reinterpret_cast<const float4*>(scratch + 256 + ni * 16 + g * 4);
-        const float4 dd = *reinterpret_cast<const float4*>(scratch + 256 + 64 + ni * 16 + g * 4);
+    for (int ni = 0; ni < 4; ++ni) {
+        cc[ni] = *reinterpret_cast<const float4*>(scratch + 256 + ni * 16 + g * 4);
+        dd[ni] = *reinterpret_cast<const float4*>(scratch + 320 + ni * 16 + g * 4);
+    }
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            acc[mi][ni][0] = fa[mi] * acc[mi][ni][0] + (fb[mi] * cc.x + dd.x);
-            acc[mi][ni][1] = fa[mi] * acc[mi][ni][1] + (fb[mi] * cc.y + dd.y);
-            acc[mi][ni][2] = fa[mi] * acc[mi][ni][2] + (fb[mi] * cc.z + dd.z);
-            acc[mi][ni][3] = fa[mi] * acc[mi][ni][3] + (fb[mi] * cc.w + dd.w);
+    for (int mi = 0; mi < MI; ++mi) {
+        const float2 ab = *reinterpret_cast<const float2*>(scratch + (mi * 16 + l15) * 2);      // row mwave + mi*16 + l15
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            acc[mi][ni][0] = ab.x * acc[mi][ni][0] + (ab.y * cc[ni].x + dd[ni].x);
+            acc[mi][ni][1] = ab.x * acc[mi][ni][1] + (ab.y * cc[ni].y + dd[ni].y);
+            acc[mi][ni][2] = ab.x * acc[mi][ni][2] + (ab.y * cc[ni].z + dd[ni].z);
+            acc[mi][ni][3] = ab.x * acc[mi][ni][3] + (ab.y * cc[ni].w + dd[ni].w);
         }
     }
 }
@@ -200,7 +141,7 @@ __device__ __forceinline__ void nt_store_row(bf16_t* p, const float (&v)[8]) {
 }
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
-template <int EPI, typename OutT, int MI, int NPRE, bool FULL = false, int RES = -1, bool EMIT = false, typename Hook = NoHook>
+template <int EPI, typename OutT, int MI, int NPRE, bool FULL = false, int RES = -1, typename Hook = NoHook>
 __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][4], unsigned char* eraw, int mwave,
                                               int nw, int lane, const float4 (&rpre)[NPRE], Hook hook = Hook()) {
     constexpr int CPL = 16 / (int)sizeof(OutT);                    // columns per lane per store (16 B)
@@ -367,6 +308,19 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         return;
     }
+    // hi/lo residual stream: residual and output are pairs of bf16 planes, 8 columns (16 B of each plane) per lane
+    constexpr bool HILO = (EPI == EPI_STD) && RES == 2 && sizeof(OutT) == 2;
+    constexpr bool PIPE_HILO = HILO && FULL;
+    [[maybe_unused]] uint4 hnext[ITERS] = {}, lnext[ITERS] = {};
+    [[maybe_unused]] const bf16_t* res_hi = reinterpret_cast<const bf16_t*>(p.residual);
+    if constexpr (PIPE_HILO) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const size_t off = (size_t)((mwave + it * RPI + lane / LPR) % p.res_rows) * p.ldr + ncol;
+            hnext[it] = *reinterpret_cast<const uint4*>(res_hi + off);
+            lnext[it] = *reinterpret_cast<const uint4*>(p.res_lo + off);
+        }
+    }
     constexpr bool PIPE_RES = (EPI == EPI_STD) && FULL && RES == 1 && NPRE == 1 && sizeof(OutT) == 4;
     float4 rnext[ITERS] = {};
     if constexpr (PIPE_RES) {
@@ -385,6 +339,19 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                 for (int it = 0; it < ITERS; ++it)
                     rnext[it] = *reinterpret_cast<const float4*>(
                         p.residual + (size_t)((mwave + (mi + 1) * 16 + it * RPI + lane / LPR) % p.res_rows) * p.ldr + ncol);
+            }
+        }
+        [[maybe_unused]] uint4 hcur[ITERS], lcur[ITERS];
+        if constexpr (PIPE_HILO) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) { hcur[it] = hnext[it]; lcur[it] = lnext[it]; }
+            if (mi + 1 < MI) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const size_t off = (size_t)((mwave + (mi + 1) * 16 + it * RPI + lane / LPR) % p.res_rows) * p.ldr + ncol;
+                    hnext[it] = *reinterpret_cast<const uint4*>(res_hi + off);
+                    lnext[it] = *reinterpret_cast<const uint4*>(p.res_lo + off);
+                }
             }
         }
         const int mbase = mwave + mi * 16;
@@ -455,6 +422,27 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                         const float4 t = *reinterpret_cast<const float4*>(ebuf + r * ESTRIDE + ccol + j);
                         v[j] = t.x + bias_v[j]; v[j + 1] = t.y + bias_v[j + 1]; v[j + 2] = t.z + bias_v[j + 2]; v[j + 3] = t.w + bias_v[j + 3];
                     }
+                    if constexpr (HILO) {
+                        uint4 rh, rl;
+                        if constexpr (PIPE_HILO) { rh = hcur[it]; rl = lcur[it]; }
+                        else {
+                            const size_t off = (size_t)(mm % p.res_rows) * p.ldr + ncol;
+                            rh = *reinterpret_cast<const uint4*>(res_hi + off);
+                            rl = *reinterpret_cast<const uint4*>(p.res_lo + off);
+                        }
+                        const unsigned hw[4] = {rh.x, rh.y, rh.z, rh.w}, lw[4] = {rl.x, rl.y, rl.z, rl.w};
+                        unsigned oh[4], ol[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {              // two columns per word; hi + lo is exact in f32
+                            const float x0 = v[2 * j] + (__uint_as_float(hw[j] << 16) + __uint_as_float(lw[j] << 16));
+                            const float x1 = v[2 * j + 1] + (__uint_as_float(hw[j] & 0xffff0000u) + __uint_as_float(lw[j] & 0xffff0000u));
+                            oh[j] = pack_bf16x2(x0, x1);
+                            ol[j] = pack_bf16x2(x0 - __uint_as_float(oh[j] << 16), x1 - __uint_as_float(oh[j] & 0xffff0000u));
+                        }
+                        nt_store16(reinterpret_cast<bf16_t*>(p.out) + (size_t)mm * p.ldo + ncol, make_uint4(oh[0], oh[1], oh[2], oh[3]));
+                        nt_store16(p.out_lo + (size_t)mm * p.ldo + ncol, make_uint4(ol[0], ol[1], ol[2], ol[3]));
+                        continue;
+                    }
                     if constexpr (sizeof(OutT) == 4 && RES != 0) {
                         if (RES == 1 || p.residual) {
                             float4 rr;
@@ -465,18 +453,6 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                         }
                     }
                     nt_store_row(reinterpret_cast<OutT*>(p.out) + (size_t)mm * p.ldo + ncol, v);
-                    if constexpr (EMIT && sizeof(OutT) == 4) {
-                        // LayerNorm fold: the consumer GEMM reads this row as bf16; its statistics come from the f32 values
-                        __builtin_nontemporal_store(nt_v2u{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, reinterpret_cast<nt_v2u*>(p.xb_out + (size_t)mm * p.ldxb + ncol));
-                        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-                        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                        s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);            // the row's 64 columns sit in 16 adjacent lanes
-                        s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);
-                        s1 += dpp_mov<0x141>(s1); s2 += dpp_mov<0x141>(s2);
-                        s1 += dpp_mov<0x140>(s1); s2 += dpp_mov<0x140>(s2);
-                        if ((lane & 15) == 0)
-                            *reinterpret_cast<float2*>(p.stats_out + ((size_t)(nw >> 6) * p.M + mm) * 2) = make_float2(s1, s2);     // [chunk][row][2]
-                    }
                 }
             }
         } else if constexpr (EPI == EPI_SWIGLU) {

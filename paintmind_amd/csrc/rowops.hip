@@ -193,32 +193,6 @@ inline int grid_for(size_t total) {
 
 }  // namespace
 
-namespace {
-__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ stats, int nc, int M, float eps, float2* __restrict__ coef) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = 0; c < nc; ++c) {                              // chunk order: deterministic
-        const float2 t = *reinterpret_cast<const float2*>(stats + ((size_t)c * M + m) * 2);
-        s1 += t.x; s2 += t.y;
-    }
-    const float invD = 1.0f / (float)(nc * 64);
-    const float mean = s1 * invD;
-    const float var = fmaxf(s2 * invD - mean * mean, 0.f);
-    const float rstd = 1.0f / sqrtf(var + eps);
-    coef[m] = make_float2(rstd, -rstd * mean);
-}
-}  // namespace
-
-int pm_ln_finalize(const float* stats, int nc, int M, float eps, float* coef, pmhip_stream stream) {
-    PM_REQUIRE(stats && coef && nc > 0 && M > 0, "ln_finalize: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    PmTimer tm(FAM_ROWOPS, s);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stats, nc, M, eps, reinterpret_cast<float2*>(coef));
-    PM_HIP(hipGetLastError());
-    return PMHIP_OK;
-}
-
 extern "C" int pmhip_layernorm(const float* x, const float* gamma, const float* beta, float eps, void* out,
                                int out_dtype, int M, int D, pmhip_stream stream) {
     PM_REQUIRE(x && gamma && beta && out, "layernorm: null pointer");
@@ -228,6 +202,191 @@ extern "C" int pmhip_layernorm(const float* x, const float* gamma, const float* 
     if (out_dtype == PMHIP_BF16) return launch_ln<bf16_t>(x, gamma, beta, eps, out, M, D, s);
     pm_set_error("layernorm: bad out dtype %d", out_dtype);
     return PMHIP_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 hi/lo residual stream (bf16-perf mode): x = hi + lo, two bf16 planes [M, D].
+//   hilo_rows_kernel  one wave per row, the row in registers.  IN: f32 row, or hi + lo.  Statistics two-pass like
+//                     layernorm_kernel.  OUT (any subset): LayerNorm(x) as f32 / bf16, LayerNorm(x) split into hi + lo,
+//                     x itself split (no normalisation), x joined to f32, or only the row's (rstd, -rstd * mean) pair
+//                     computed from the HI plane alone -- what a GEMM that consumes hi with the LayerNorm folded in needs
+//                     (it multiplies bf16(x) = hi, so the statistics of hi are the self-consistent ones).
+// ------------------------------------------------------------------------------------------------
+enum { HL_LN_F32 = 0, HL_LN_BF16 = 1, HL_LN_HILO = 2, HL_SPLIT = 3, HL_JOIN = 4, HL_COEF = 5 };
+
+template <bool IN_HILO, int MODE>
+__global__ __launch_bounds__(THREADS) void hilo_rows_kernel(const float* __restrict__ x, const bf16_t* __restrict__ xh,
+                                                            const bf16_t* __restrict__ xl, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, void* __restrict__ out,
+                                                            bf16_t* __restrict__ out_lo, int M, int D) {
+    constexpr int MAXV = 4;                                      // 4 columns per lane per step, D <= 1024
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const size_t base = (size_t)row * D;
+    const int nv = (D + 255) / 256;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = (i * 64 + lane) * 4;
+        if (i < nv && c0 < D) {
+            if constexpr (IN_HILO) {
+                const uint2 h = *reinterpret_cast<const uint2*>(xh + base + c0);
+                uint2 l = make_uint2(0u, 0u);
+                if constexpr (MODE != HL_COEF) l = *reinterpret_cast<const uint2*>(xl + base + c0);
+                v[i].x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
+                v[i].y = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
+                v[i].z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
+                v[i].w = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+            } else {
+                v[i] = *reinterpret_cast<const float4*>(x + base + c0);
+            }
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if constexpr (MODE != HL_SPLIT && MODE != HL_JOIN) {
+        const float invD = 1.0f / (float)D;
+        mean = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c0 = (i * 64 + lane) * 4;
+            if (i < nv && c0 < D) {
+                const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                q += (a * a + b * b) + (c * c + d * d);
+            }
+        }
+        rstd = 1.0f / sqrtf(wave_sum(q) * invD + eps);
+    }
+    if constexpr (MODE == HL_COEF) {
+        if (lane == 0) *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + (size_t)row * 2) = make_float2(rstd, -rstd * mean);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c0 = (i * 64 + lane) * 4;
+        if (i < nv && c0 < D) {
+            float4 y = v[i];
+            if constexpr (MODE == HL_LN_F32 || MODE == HL_LN_BF16 || MODE == HL_LN_HILO) {
+                const float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
+                const float4 bt = *reinterpret_cast<const float4*>(beta + c0);
+                y = make_float4((v[i].x - mean) * rstd * gm.x + bt.x, (v[i].y - mean) * rstd * gm.y + bt.y,
+                                (v[i].z - mean) * rstd * gm.z + bt.z, (v[i].w - mean) * rstd * gm.w + bt.w);
+            }
+            if constexpr (MODE == HL_LN_F32 || MODE == HL_JOIN) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + base + c0) = y;
+            } else if constexpr (MODE == HL_LN_BF16) {
+                store4(reinterpret_cast<bf16_t*>(out) + base + c0, y.x, y.y, y.z, y.w);
+            } else {                                             // split into hi + lo
+                const uint2 h = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+                const uint2 l = make_uint2(pack_bf16x2(y.x - __uint_as_float(h.x << 16), y.y - __uint_as_float(h.x & 0xffff0000u)),
+                                           pack_bf16x2(y.z - __uint_as_float(h.y << 16), y.w - __uint_as_float(h.y & 0xffff0000u)));
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + base + c0) = h;
+                *reinterpret_cast<uint2*>(out_lo + base + c0) = l;
+            }
+        }
+    }
+}
+
+// (rstd, -rstd * mean) of the rows of the hi plane alone.  RPW rows per wave, every row's 16-byte loads issued before the
+// first is consumed (a wave with one 1-KiB row in flight is latency-bound: 3.9 TB/s); two-pass statistics in registers.
+template <int RPW>
+__global__ __launch_bounds__(THREADS) void ln_coef_kernel(const bf16_t* __restrict__ xh, float eps, float2* __restrict__ coef, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= M) return;
+    uint4 u[RPW][2];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r < M ? row0 + r : M - 1;
+        const bf16_t* xr = xh + (size_t)row * D;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c0 = (i * 64 + lane) * 8;
+            u[r][i] = make_uint4(0u, 0u, 0u, 0u);
+            if (c0 < D) u[r][i] = *reinterpret_cast<const uint4*>(xr + c0);
+        }
+    }
+    const float invD = 1.0f / (float)D;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float v[2][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned w[4] = {u[r][i].x, u[r][i].y, u[r][i].z, u[r][i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[i][2 * j] = __uint_as_float(w[j] << 16); v[i][2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+            s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));     // absent chunks are zeros
+        }
+        const float mean = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if ((i * 64 + lane) * 8 < D) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float a = v[i][j] - mean; q += a * a; }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * invD + eps);
+        if (lane == 0 && row0 + r < M) coef[row0 + r] = make_float2(rstd, -rstd * mean);
+    }
+}
+
+template <bool IN_HILO, int MODE>
+static int launch_hilo(const float* x, const void* xh, const void* xl, const float* g, const float* b, float eps, void* out, void* out_lo,
+                       int M, int D, hipStream_t s) {
+    PM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "hi/lo row operator: D=%d must be a multiple of 4, <= 1024", D);
+    PmTimer tm(FAM_LAYERNORM, s);
+    hipLaunchKernelGGL((hilo_rows_kernel<IN_HILO, MODE>), dim3(ceil_div(M, THREADS / 64)), dim3(THREADS), 0, s, x,
+                       reinterpret_cast<const bf16_t*>(xh), reinterpret_cast<const bf16_t*>(xl), g, b, eps, out,
+                       reinterpret_cast<bf16_t*>(out_lo), M, D);
+    PM_HIP(hipGetLastError());
+    return PMHIP_OK;
+}
+
+// LayerNorm of a hi/lo row -> f32 or bf16 (the unfolded consumer path: small batches, the decoder's final norm)
+extern "C" int pmhip_layernorm_hilo(const void* x_hi, const void* x_lo, const float* gamma, const float* beta, float eps, void* out,
+                                    int out_dtype, int M, int D, pmhip_stream stream) {
+    PM_REQUIRE(x_hi && x_lo && gamma && beta && out, "layernorm_hilo: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == PMHIP_F32) return launch_hilo<true, HL_LN_F32>(nullptr, x_hi, x_lo, gamma, beta, eps, out, nullptr, M, D, s);
+    if (out_dtype == PMHIP_BF16) return launch_hilo<true, HL_LN_BF16>(nullptr, x_hi, x_lo, gamma, beta, eps, out, nullptr, M, D, s);
+    pm_set_error("layernorm_hilo: bad out dtype %d", out_dtype);
+    return PMHIP_EINVAL;
+}
+
+// LayerNorm of an f32 row, result split into hi + lo (the encoder's norm_pre opens the residual stream)
+extern "C" int pmhip_layernorm_to_hilo(const float* x, const float* gamma, const float* beta, float eps, void* out_hi, void* out_lo,
+                                       int M, int D, pmhip_stream stream) {
+    PM_REQUIRE(x && gamma && beta && out_hi && out_lo, "layernorm_to_hilo: null pointer");
+    return launch_hilo<false, HL_LN_HILO>(x, nullptr, nullptr, gamma, beta, eps, out_hi, out_lo, M, D, (hipStream_t)stream);
+}
+
+// x (f32) -> hi + lo, and back
+extern "C" int pmhip_split_hilo(const float* x, void* out_hi, void* out_lo, int M, int D, pmhip_stream stream) {
+    PM_REQUIRE(x && out_hi && out_lo, "split_hilo: null pointer");
+    return launch_hilo<false, HL_SPLIT>(x, nullptr, nullptr, nullptr, nullptr, 0.f, out_hi, out_lo, M, D, (hipStream_t)stream);
+}
+extern "C" int pmhip_join_hilo(const void* x_hi, const void* x_lo, float* out, int M, int D, pmhip_stream stream) {
+    PM_REQUIRE(x_hi && x_lo && out, "join_hilo: null pointer");
+    return launch_hilo<true, HL_JOIN>(nullptr, x_hi, x_lo, nullptr, nullptr, 0.f, out, nullptr, M, D, (hipStream_t)stream);
+}
+
+// per-row (rstd, -rstd * mean) of the hi plane: the coefficients of a GEMM with the LayerNorm folded in (pmhip_lnfold)
+extern "C" int pmhip_ln_coef(const void* x_hi, float eps, float* coef, int M, int D, pmhip_stream stream) {
+    PM_REQUIRE(x_hi && coef, "ln_coef: null pointer");
+    PM_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 1024, "ln_coef: D=%d must be a multiple of 8, <= 1024", D);
+    hipStream_t s = (hipStream_t)stream;
+    PmTimer tm(FAM_LAYERNORM, s);
+    constexpr int RPW = 4;
+    hipLaunchKernelGGL((ln_coef_kernel<RPW>), dim3(ceil_div(M, (THREADS / 64) * RPW)), dim3(THREADS), 0, s,
+                       reinterpret_cast<const bf16_t*>(x_hi), eps, reinterpret_cast<float2*>(coef), M, D);
+    PM_HIP(hipGetLastError());
+    return PMHIP_OK;
 }
 
 extern "C" int pmhip_patchify(const float* img, void* out, int out_dtype, int B, int C, int H, int W, int P,

@@ -114,30 +114,81 @@ def gemm_heads(a, w, heads, tokens, kinds, q_scale=1.0, dim_head=64):
     return outs
 
 
-# ---- LayerNorm folded into the neighbouring GEMMs (include/pmhip.h, pmhip_lnfold) ---------------------------------
-def gemm_stats(a, w, bias=None, residual=None, res_rows=0):
-    """f32 GEMM that also emits the bf16 copy of its result and the per-64-column (sum x, sum x^2) partials."""
-    dev = _dev(a, w, bias, residual)
+# ---- bf16 hi/lo residual stream + LayerNorm folded into the consuming GEMM (include/pmhip.h, pmhip_lnfold) ------------
+def split_hilo(x):
+    """x f32 [M,D] -> (hi, lo) bf16 planes with x = hi + lo"""
+    dev = _dev(x)
+    lib = _lib.load()
+    M, D = x.shape
+    hi = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    lo = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_split_hilo(_p(x), _p(hi), _p(lo), M, D, stream_ptr(dev)), "pmhip_split_hilo")
+    return hi, lo
+
+
+def join_hilo(hi, lo):
+    dev = _dev(hi, lo)
+    lib = _lib.load()
+    M, D = hi.shape
+    out = torch.empty(M, D, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_join_hilo(_p(hi), _p(lo), _p(out), M, D, stream_ptr(dev)), "pmhip_join_hilo")
+    return out
+
+
+def gemm_hilo(a, w, res_hi, res_lo, bias=None, res_rows=0):
+    """(hi, lo) = split(a @ w^T + bias + (res_hi + res_lo)[m % res_rows]); bf16 operands"""
+    dev = _dev(a, w, res_hi, res_lo)
     lib = _lib.load()
     M, K = a.shape
     N = w.shape[0]
-    out = torch.empty(M, N, device=dev, dtype=torch.float32)
-    xb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    stats = torch.empty(N // 64, M, 2, device=dev, dtype=torch.float32)      # chunk-major
-    ldr = residual.shape[-1] if residual is not None else 0
-    rr = res_rows or (residual.shape[0] if residual is not None else 0)
+    hi = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    lo = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     with torch.cuda.device(dev):
-        check(lib.pmhip_gemm_stats(pm_dtype(a.dtype), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(residual), ldr, rr,
-                                   _p(out), N, _p(xb), N, _p(stats), M, N, K, stream_ptr(dev)), "pmhip_gemm_stats")
-    return out, xb, stats
+        check(lib.pmhip_gemm_hilo(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(res_hi), _p(res_lo), res_hi.stride(0),
+                                  int(res_rows), _p(hi), _p(lo), N, M, N, K, stream_ptr(dev)), "pmhip_gemm_hilo")
+    return hi, lo
 
 
-def _lnfold(stats, c, d, eps):
+def layernorm_hilo(hi, lo, gamma, beta, eps=1e-5, out_dtype=torch.bfloat16):
+    dev = _dev(hi, lo, gamma, beta)
+    lib = _lib.load()
+    M, D = hi.shape
+    out = torch.empty(M, D, device=dev, dtype=out_dtype)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_layernorm_hilo(_p(hi), _p(lo), _p(gamma), _p(beta), float(eps), _p(out), pm_dtype(out_dtype), M, D,
+                                       stream_ptr(dev)), "pmhip_layernorm_hilo")
+    return out
+
+
+def layernorm_to_hilo(x, gamma, beta, eps=1e-5):
+    dev = _dev(x, gamma, beta)
+    lib = _lib.load()
+    M, D = x.shape
+    hi = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    lo = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_layernorm_to_hilo(_p(x), _p(gamma), _p(beta), float(eps), _p(hi), _p(lo), M, D, stream_ptr(dev)),
+              "pmhip_layernorm_to_hilo")
+    return hi, lo
+
+
+def ln_coef(hi, eps=1e-5):
+    """per-row (rstd, -rstd * mean) of the hi plane -> f32 [M,2]"""
+    dev = _dev(hi)
+    lib = _lib.load()
+    M, D = hi.shape
+    coef = torch.empty(M, 2, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_ln_coef(_p(hi), float(eps), _p(coef), M, D, stream_ptr(dev)), "pmhip_ln_coef")
+    return coef
+
+
+def _lnfold(coef, c, d):
     ln = _lib.LnFold()
-    ln.stats, ln.c, ln.d, ln.eps = C.c_void_p(stats.data_ptr()), C.c_void_p(c.data_ptr()), C.c_void_p(d.data_ptr()), float(eps)
-    coef = torch.empty(stats.shape[1], 2, device=stats.device, dtype=torch.float32)     # scratch: (rstd, -rstd * mean) per row
-    ln.coef = C.c_void_p(coef.data_ptr())
-    ln._keep = coef
+    ln.coef, ln.c, ln.d = coef.data_ptr(), c.data_ptr(), d.data_ptr()
+    ln._keep = (coef, c, d)
     return ln
 
 
@@ -145,34 +196,34 @@ def lnfold_supported(kind, M, N, K):
     return bool(_lib.load().pmhip_lnfold_supported(BF16, kind, M, N, K))
 
 
-def gemm_ln(xb, wg, stats, c, d, eps=1e-5, bias=None, out_dtype=None):
-    dev = _dev(xb, wg, stats, c, d)
+def gemm_ln(xb, wg, coef, c, d, bias=None, out_dtype=None):
+    dev = _dev(xb, wg, coef, c, d)
     lib = _lib.load()
     M, K = xb.shape
     N = wg.shape[0]
     out_dtype = out_dtype or xb.dtype
     out = torch.empty(M, N, device=dev, dtype=out_dtype)
-    ln = _lnfold(stats, c, d, eps)
+    ln = _lnfold(coef, c, d)
     with torch.cuda.device(dev):
         check(lib.pmhip_gemm_ln(pm_dtype(xb.dtype), _p(xb), xb.stride(0), _p(wg), wg.stride(0), _p(bias), _p(out), N,
                                 pm_dtype(out_dtype), M, N, K, C.byref(ln), stream_ptr(dev)), "pmhip_gemm_ln")
     return out
 
 
-def gemm_swiglu_ln(xb, w12pg, b12p, stats, c, d, eps=1e-5):
+def gemm_swiglu_ln(xb, w12pg, b12p, coef, c, d):
     dev = _dev(xb, w12pg, b12p)
     lib = _lib.load()
     M, K = xb.shape
     Hp = w12pg.shape[0] // 2
     out = torch.empty(M, Hp, device=dev, dtype=xb.dtype)
-    ln = _lnfold(stats, c, d, eps)
+    ln = _lnfold(coef, c, d)
     with torch.cuda.device(dev):
         check(lib.pmhip_gemm_swiglu_ln(pm_dtype(xb.dtype), _p(xb), xb.stride(0), _p(w12pg), _p(b12p), _p(out), Hp, M, Hp, K,
                                        C.byref(ln), stream_ptr(dev)), "pmhip_gemm_swiglu_ln")
     return out
 
 
-def gemm_heads_ln(xb, wg, heads, tokens, kinds, q_scale, stats, c, d, eps=1e-5):
+def gemm_heads_ln(xb, wg, heads, tokens, kinds, q_scale, coef, c, d):
     dev = _dev(xb, wg)
     lib = _lib.load()
     M, K = xb.shape
@@ -184,7 +235,7 @@ def gemm_heads_ln(xb, wg, heads, tokens, kinds, q_scale, stats, c, d, eps=1e-5):
         outs.append(torch.zeros(shape, device=dev, dtype=xb.dtype))
     kinds_c = (C.c_int * len(kinds))(*kinds)
     outs_c = (C.c_void_p * len(kinds))(*[o.data_ptr() for o in outs])
-    ln = _lnfold(stats, c, d, eps)
+    ln = _lnfold(coef, c, d)
     with torch.cuda.device(dev):
         check(lib.pmhip_gemm_heads_ln(pm_dtype(xb.dtype), _p(xb), xb.stride(0), _p(wg), wg.stride(0), M, K, heads, tokens, tp,
                                       len(kinds), kinds_c, outs_c, float(q_scale), C.byref(ln), stream_ptr(dev)),

@@ -97,49 +97,80 @@ def test_swiglu_and_heads_large_tile_kernel():
     assert rel_err(n(vt), full[:, :, 2].transpose(0, 2, 3, 1)) < 1e-2
 
 
-def test_gemm_stats_without_residual_on_a_large_tile_shape():
-    """pmhip_gemm_stats with residual == NULL on a shape the 256x256 / two-workgroup kernels would take: those only emit the
-    bf16 copy and the statistics from their residual epilogue, so the request must be served by the kernel that handles it
-    (round-2 advisor finding: the outputs stayed unwritten)."""
-    M, D, K0 = 65536 // 8, 512, 512
+def test_hilo_row_operators():
+    """x = hi + lo as two bf16 planes: the split is exact to 2^-17 |x|, joins back, and LayerNorm of the pair equals LayerNorm of x"""
     bf = torch.bfloat16
-    a, w0, b0 = bf16_round(rnd(M, K0)), bf16_round(rnd(D, K0, scale=K0 ** -0.5)), rnd(D)
-    out, xb, stats = ops.gemm_stats(t(a, bf), t(w0, bf), bias=t(b0), residual=None)
-    plain = ops.gemm(t(a, bf), t(w0, bf), bias=t(b0), out_dtype=torch.float32)
-    assert torch.equal(out, plain) and torch.equal(xb, out.to(bf))
-    x = n(out).astype(np.float64).reshape(M, D // 64, 64)
-    assert rel_err(n(stats)[..., 0].T, x.sum(-1)) < 1e-5 and rel_err(n(stats)[..., 1].T, (x ** 2).sum(-1)) < 1e-5
+    for M, D in ((300, 512), (64, 768), (129, 1024), (7, 64), (5, 72)):
+        x = rnd(M, D, scale=3.0) + 0.9
+        hi, lo = ops.split_hilo(t(x))
+        assert torch.equal(hi, t(x).to(bf))                                   # hi IS bf16(x): what the next GEMM multiplies
+        back = n(ops.join_hilo(hi, lo))
+        assert np.max(np.abs(back - x) / np.abs(x).max()) < 2.0 ** -16
+        gamma, beta = 1 + 0.3 * rnd(D), 0.2 * rnd(D)
+        x64 = back.astype(np.float64)
+        y64 = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * gamma + beta
+        assert maxabs(n(ops.layernorm_hilo(hi, lo, t(gamma), t(beta), out_dtype=torch.float32)), y64) < 2e-5
+        assert rel_err(n(ops.layernorm_hilo(hi, lo, t(gamma), t(beta), out_dtype=bf)), y64) < 1e-2
+        yh, yl = ops.layernorm_to_hilo(t(x), t(gamma), t(beta))
+        want = n(ops.layernorm(t(x), t(gamma), t(beta)))
+        assert maxabs(n(ops.join_hilo(yh, yl)), want) < 1e-4
+        assert float((yh.float() - t(want).to(bf).float()).abs().max()) <= 2.0 ** -7 * float(np.abs(want).max())   # one bf16 ulp
+        # coefficients of the folded consumer: statistics of the hi plane
+        h64 = n(hi.float()).astype(np.float64)
+        rstd = 1.0 / np.sqrt(h64.var(1) + 1e-5)
+        coef = n(ops.ln_coef(hi))
+        assert rel_err(coef[:, 0], rstd) < 1e-5 and maxabs(coef[:, 1], -rstd * h64.mean(1)) < 1e-4
 
 
-def test_layernorm_fold_producer_and_consumers():
-    """LayerNorm folded into its neighbour GEMMs (stage1/layers.py:54-58: every projection consumes LN(x)).
-    Producer: the residual GEMM also emits bf16(x) and the per-64-column (sum, sum of squares) partials -- the f32 result
-    must be bit-identical to the plain GEMM.  Consumers (plain / SwiGLU / head split): raw bf16 rows x gamma-scaled
-    weights + the epilogue formula against the float64 LayerNorm -> Linear, and against the unfused bf16 kernels."""
-    M, D, K0, heads = 4096, 512, 512, 8
+@pytest.mark.parametrize("M,N,K,rows", [(65536 // 8, 512, 512, 0),      # two-workgroup kernel (short-K residual GEMM)
+                                         (8192, 512, 1408, 0),          # 256x256 kernel (long K)
+                                         (2048, 512, 64, 1024),         # 128x128 kernel, position-embedding addend (row modulo)
+                                         (200, 768, 192, 0)])           # ragged M
+def test_gemm_hilo_residual_stream(M, N, K, rows):
+    """(hi, lo) <- split(A W^T + bias + (hi + lo)): every kernel route, against float64; in place like the engine uses it"""
     bf = torch.bfloat16
-    a, w0, b0 = bf16_round(rnd(M, K0)), bf16_round(rnd(D, K0, scale=K0 ** -0.5)), rnd(D)
-    res = rnd(M, D) + 0.7                                   # non-zero row means
-    out, xb, stats = ops.gemm_stats(t(a, bf), t(w0, bf), bias=t(b0), residual=t(res))
-    plain = ops.gemm(t(a, bf), t(w0, bf), bias=t(b0), residual=t(res), out_dtype=torch.float32)
-    assert torch.equal(out, plain) and torch.equal(xb, out.to(bf))
-    x = n(out).astype(np.float64)
-    chunks = x.reshape(M, D // 64, 64)
-    assert rel_err(n(stats)[..., 0].T, chunks.sum(-1)) < 1e-5 and rel_err(n(stats)[..., 1].T, (chunks ** 2).sum(-1)) < 1e-5
+    a, w, b0 = bf16_round(rnd(M, K)), bf16_round(rnd(N, K, scale=K ** -0.5)), rnd(N)
+    R = rows or M
+    res = rnd(R, N, scale=2.0) + 0.5
+    rh, rl = ops.split_hilo(t(res))
+    r64 = n(ops.join_hilo(rh, rl)).astype(np.float64)
+    want = a.astype(np.float64) @ w.astype(np.float64).T + b0 + r64[np.arange(M) % R]
+    hi, lo = ops.gemm_hilo(t(a, bf), t(w, bf), rh, rl, bias=t(b0), res_rows=rows)
+    got = n(ops.join_hilo(hi, lo)).astype(np.float64)
+    assert np.max(np.abs(got - want)) < 2e-5 * max(1.0, np.abs(want).max()), np.max(np.abs(got - want))
+    assert bool((lo.float().abs() <= hi.float().abs() * 2.0 ** -8 + 1e-30).all())     # lo is the rounding remainder of hi
+    # same value as the fp32-stream kernel up to the pair's 2^-17 resolution
+    plain = n(ops.gemm(t(a, bf), t(w, bf), bias=t(b0), residual=ops.join_hilo(rh, rl), res_rows=rows, out_dtype=torch.float32))
+    assert np.max(np.abs(got - plain)) < 2.0 ** -15 * np.abs(plain).max()
+
+
+def test_layernorm_fold_consumers():
+    """LayerNorm folded into the GEMM that consumes it (stage1/layers.py:54-58: every projection consumes LN(x)): the hi plane
+    times gamma-scaled weights + the epilogue formula with pmhip_ln_coef's coefficients, against the float64
+    LayerNorm -> Linear of the represented x, and against the unfolded bf16 kernels (plain / head split / SwiGLU)."""
+    M, D, heads = 4096, 512, 8
+    bf = torch.bfloat16
+    x = rnd(M, D) + 0.7                                     # non-zero row means
+    hi, lo = ops.split_hilo(t(x))
+    coef = ops.ln_coef(hi)
     gamma, beta = 1 + 0.3 * rnd(D), 0.2 * rnd(D)
-    y64 = (x - x.mean(1, keepdims=True)) / np.sqrt(x.var(1, keepdims=True) + 1e-5) * gamma + beta
-    y_dev = ops.layernorm(out, t(gamma), t(beta), out_dtype=bf)
+    x64 = n(ops.join_hilo(hi, lo)).astype(np.float64)
+    y64 = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * gamma + beta
+    y_dev = ops.layernorm_hilo(hi, lo, t(gamma), t(beta), out_dtype=bf)
     # plain consumer (N = 1536 -> 96 tiles of 256x256), f32 result with bias
     w1, b1 = bf16_round(rnd(1536, D, scale=D ** -0.5)), rnd(1536)
     wg, c, d = packing.ln_fold(t(w1), t(gamma), t(beta))
-    got = n(ops.gemm_ln(xb, wg, stats, c, d, bias=t(b1), out_dtype=torch.float32))
+    got = n(ops.gemm_ln(hi, wg, coef, c, d, bias=t(b1), out_dtype=torch.float32))
     want = y64 @ w1.astype(np.float64).T + b1
     unfused = n(ops.gemm(y_dev, t(w1, bf), bias=t(b1), out_dtype=torch.float32))
     assert rel_err(got, want) < 2e-2 and rel_err(unfused, want) < 2e-2, (rel_err(got, want), rel_err(unfused, want))
-    assert ops.lnfold_supported(0, M, 1536, D) and not ops.lnfold_supported(0, 256, 1536, D)
+    # served at ANY tile count (folded or not may not depend on the batch size): 256 rows alone give the same bits
+    assert ops.lnfold_supported(0, M, 1536, D) and ops.lnfold_supported(0, 256, 1536, D)
+    assert not ops.lnfold_supported(0, 200, 1536, D) and not ops.lnfold_supported(0, M, 192, D)
+    small = ops.gemm_ln(hi[:256].contiguous(), wg, coef[:256].contiguous(), c, d, bias=t(b1), out_dtype=torch.float32)
+    assert np.array_equal(n(small), got[:256])
     # head split (q | k | v)
-    wg, c, d = packing.ln_fold(t(w1), t(gamma), t(beta))
-    q, k, vt = ops.gemm_heads_ln(xb, wg, heads, 1024, [ops.PART_Q, ops.PART_K, ops.PART_V], 0.125, stats, c, d)
+    q, k, vt = ops.gemm_heads_ln(hi, wg, heads, 1024, [ops.PART_Q, ops.PART_K, ops.PART_V], 0.125, coef, c, d)
     q2, k2, vt2 = ops.gemm_heads(y_dev, t(w1, bf), heads, 1024, [ops.PART_Q, ops.PART_K, ops.PART_V], 0.125)
     proj = (y64 @ w1.astype(np.float64).T).reshape(4, 1024, 3, heads, 64)
     assert rel_err(n(q), proj[:, :, 0].transpose(0, 2, 1, 3) * 0.125) < 2e-2
@@ -149,7 +180,7 @@ def test_layernorm_fold_producer_and_consumers():
     lin = torch.nn.Linear(D, 2 * 1368)
     w12p32, b12p, hp = packing.pack_w12(lin.to(dev()), torch.float32)
     wg, c, d = packing.ln_fold(w12p32, t(gamma), t(beta))
-    hid = n(ops.gemm_swiglu_ln(xb, wg, b12p, stats, c, d))
+    hid = n(ops.gemm_swiglu_ln(hi, wg, b12p, coef, c, d))
     hid2 = n(ops.gemm_swiglu(y_dev, w12p32.to(bf), b12p))
     w12, b12 = n(lin.weight).astype(np.float64), n(lin.bias).astype(np.float64)
     x12 = y64 @ w12.T + b12
