@@ -377,17 +377,18 @@ def cpu_baseline(workload):
                        f"of the reference; value_b8: B=8 timed on 2 of the {T} steps (all steps cost the same) and scaled to {T}")
 
 
-def pmc_traffic(workload, dtype):
-    """HBM bytes per GEMM launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc runs of this same command, read side doubled per the gfx950 correction).
-    Only valid for the configuration it was collected on."""
+def pmc_traffic(workload, dtype, family):
+    """HBM bytes per launch of a kernel family from the newest committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command by tools/profile_round.sh, read side
+    doubled per the gfx950 correction).  NOT measured in this run; only valid for the configuration it was collected on."""
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if workload != DEFAULT_WORKLOAD or dtype != "bf16" or not paths:
         return None
     try:
-        fam = json.load(open(paths[-1]))["families"]["gemm"]
+        fam = json.load(open(paths[-1]))["families"][family]
         return {"hbm_bytes_per_launch": round(fam["hbm_bytes_per_launch"]), "read": round(fam["hbm_read_bytes_per_launch"]),
-                "write": round(fam["hbm_write_bytes_per_launch"]), "source": os.path.relpath(paths[-1], ROOT)}
+                "write": round(fam["hbm_write_bytes_per_launch"]), "source": os.path.relpath(paths[-1], ROOT),
+                "note": "from the committed profile of this command (tools/profile_round.sh), not collected in this run"}
     except Exception:
         return None
 
@@ -606,20 +607,37 @@ def main():
         ops.timing_enable(False)
         fam = {f: ops.timing_get(f) for f in ("gemm", "attention", "layernorm", "sample", "vq", "rowops")}
         n_g, ms_g = fam["gemm"]
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        ach = gf / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
-        result["roofline"] = {
-            "kernel": "GEMM family (gemm256_kernel + gemm2b_kernel + gemm_nt_kernel, all launches of one step)", "bound": "mfma",
-            "achieved": round(ach, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(args.workload, args.dtype), "launches": n_g,
-            "avg_launch_ms": round(ms_g / max(n_g, 1), 4), "algorithmic_gflop_per_launch": round(gf / max(n_g, 1) / 1e9, 2)}
         n_a, ms_a = fam["attention"]
         n_s, ms_s = fam["sample"]
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        ach_g = gf / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
+        ach_a = af / (ms_a * 1e-3) / 1e12 if ms_a > 0 else 0.0
+        # `roofline`: the dominant single kernel = the fused attention kernel (the largest share of GPU time of any one
+        # kernel; the GEMM time is spread over three kernels and five epilogues).  Algorithmic work per launch:
+        # 4 * Nq * Nkv * inner flops; the row-sum MFMAs the kernel adds (1/8 more) are NOT counted.
+        gemm_block = {
+            "kernel": "GEMM family (gemm256_kernel + gemm2b_kernel + gemm_nt_kernel, all launches of one step)", "bound": "mfma",
+            "achieved": round(ach_g, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach_g / peak, 4),
+            "traffic": pmc_traffic(args.workload, args.dtype, "gemm"), "launches": n_g,
+            "avg_launch_ms": round(ms_g / max(n_g, 1), 4), "algorithmic_gflop_per_launch": round(gf / max(n_g, 1) / 1e9, 2)}
+        attn_block = {
+            "kernel": "attention_bf16_kernel (softmax(QK^T)V, all launches of one step: stage-2 self-attention x2 per layer + ViT decoder)"
+                      if args.dtype == "bf16" else "attention_kernel<float>", "bound": "mfma",
+            "achieved": round(ach_a, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach_a / peak, 4),
+            "traffic": pmc_traffic(args.workload, args.dtype, "attention"), "launches": n_a,
+            "avg_launch_ms": round(ms_a / max(n_a, 1), 4), "algorithmic_gflop_per_launch": round(af / max(n_a, 1) / 1e9, 2)}
+        if pipeline and n_a > 0:
+            result["roofline"] = attn_block
+            result["roofline_gemm_family"] = gemm_block
+        else:
+            result["roofline"] = gemm_block
         result["kernel_families"] = {
             f: {"launches": fam[f][0], "ms": round(fam[f][1], 3)} for f in fam}
         if ms_a > 0:
-            result["kernel_families"]["attention"]["tflops"] = round(af / (ms_a * 1e-3) / 1e12, 2)
-            result["kernel_families"]["attention"]["frac_of_bf16_peak"] = round(af / (ms_a * 1e-3) / 1e12 / peak, 4)
+            result["kernel_families"]["attention"]["tflops"] = round(ach_a, 2)
+            result["kernel_families"]["attention"]["frac_of_bf16_peak"] = round(ach_a / peak, 4)
+        if ms_g > 0:
+            result["kernel_families"]["gemm"]["tflops"] = round(ach_g, 2)
         if ms_s > 0 and sample_bytes:
             result["kernel_families"]["sample"]["logits_GBps"] = round(sample_bytes / (ms_s * 1e-3) / 1e9, 1)
         result["end_to_end_tflops_per_gpu"] = round((gf + af) / (ms_per_step * 1e-3) / 1e12, 2)

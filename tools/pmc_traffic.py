@@ -17,7 +17,7 @@ def family(name):
         return "gemm"
     if "attention" in name:
         return "attention"
-    if "layernorm" in name:
+    if "layernorm" in name or "ln_coef" in name or "hilo_rows" in name:
         return "layernorm"
     if "sample_rows" in name or "remask" in name:
         return "sample"
