@@ -173,6 +173,17 @@ int check_dim_head(const char* who, const pmhip_tower_cfg& tc) {
     return PMHIP_OK;
 }
 
+// The bf16 hi/lo residual stream + folded LayerNorm is OPT-IN (PMHIP_HILO=1, read on every forward): it is 1.3 % faster on
+// the default workload (same box: 476.5 vs 470.6 images/s) and as accurate, but with concurrent lanes 3-11 of 1800
+// generate() calls of the text-conditioned configurations were not bit-identical to the single-stream result
+// (tools/generate_race_stress.py; never in 1800 calls with PMHIP_LN_UNFOLD=1 or with the fp32 stream).  One instance was
+// caught at operator level after 120 000 launches on three streams (tools/fold_race_stress.py): a folded logits GEMM with ONE
+// accumulator register wrong in one 16-lane group (16 rows x 1 column).  Not root-caused; DESIGN.md section 4d.
+bool hilo_enabled() {
+    const char* e = getenv("PMHIP_HILO");
+    return e && atoi(e) != 0;
+}
+
 bool ln_fold_enabled() {
     const char* e = getenv("PMHIP_LN_UNFOLD");
     return !(e && atoi(e) != 0);
@@ -184,11 +195,7 @@ int alloc_tower(Workspace& ws, const char* tag, int dtype, const pmhip_tower_cfg
     const size_t M = (size_t)B * tokens;
     const int dh = dh_of(tc), inner = tc.heads * dh, Np = round_up(tokens, 64);
     std::string t(tag);
-    // development switch for same-box comparisons: PMHIP_F32_STREAM=1 keeps the fp32 residual stream + LayerNorm kernel of
-    // rounds 1-2 in bf16 mode
-    static int f32_stream = -1;
-    if (f32_stream < 0) { const char* e = getenv("PMHIP_F32_STREAM"); f32_stream = e ? atoi(e) : 0; }
-    b.hilo = dtype == PMHIP_BF16 && !f32_stream;
+    b.hilo = dtype == PMHIP_BF16 && hilo_enabled();
     if (b.hilo) {
         WS(ws, (t + ".xh").c_str(), M * tc.dim * 2, b.xh);
         WS(ws, (t + ".xl").c_str(), M * tc.dim * 2, b.xl);
@@ -439,8 +446,13 @@ extern "C" int pmhip_vqgan_encode(pmhip_vqgan* h, const float* img, int B, float
     const int M = B * h->tokens, dim = c.enc.dim, E = c.embed_dim;
     TowerBufs tb;
     PM_TRY(vq_encoder(h, img, B, tb, s));
-    // prev_quant acts on the raw residual stream (vqmodel.py:23): in bf16 mode its operand bf16(x) is the hi plane
+    // prev_quant acts on the raw residual stream (vqmodel.py:23): cast it to T when T != f32 (with the hi/lo stream the
+    // operand bf16(x) is the hi plane itself)
     const void* xin = tb.hilo ? tb.xh : (const void*)tb.x;
+    if (!tb.hilo && h->dtype != PMHIP_F32) {
+        PM_TRY(pmhip_convert_pad(tb.x, dim, tb.y, h->dtype, dim, M, s));
+        xin = tb.y;
+    }
     float* ze; void* scratch;
     WS(h->ws, "enc.ze", (size_t)M * E * 4, ze);
     WS(h->ws, "enc.vq", pmhip_vq_scratch_bytes(M, c.n_embed), scratch);
@@ -766,7 +778,7 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
 
     std::string key = "B" + std::to_string(B) + "T" + std::to_string(T) + "k" + std::to_string(topk) + "L" +
                       std::to_string(context ? L : 0) + "v" + std::to_string(vq ? vq->uid : 0) + "f" +
-                      std::to_string(ln_fold_enabled() ? 1 : 0) + "d";
+                      std::to_string((hilo_enabled() ? 2 : 0) + (ln_fold_enabled() ? 1 : 0)) + "d";
     for (int t = 0; t < T; ++t) key += (decode_host && decode_host[t]) ? '1' : '0';
     GraphEntry& ge = s2->graphs[key];
 

@@ -140,7 +140,12 @@ __device__ __forceinline__ void k_tile(const GemmParams& p, const LoopCtx& c, un
     // LayerNorm fold: the tile's per-row coefficients are DMA'd into the wave's scratch in the first read slot of its LAST
     // K-tile (LN_COEF_LOADS more operations in flight through phases 1 and 2, older than the phase's DMA) and are retired by
     // the closing vmcnt(0)
-    constexpr int XL = (FOLD && KIND == KT_LAST) ? LN_COEF_LOADS : 0;
+#ifdef PM_FOLD_DIRECT
+    constexpr bool FOLD_DIRECT = true;
+#else
+    constexpr bool FOLD_DIRECT = false;
+#endif
+    constexpr int XL = (FOLD && !FOLD_DIRECT && KIND == KT_LAST) ? LN_COEF_LOADS : 0;
     constexpr bool FIRST = KIND == KT_FIRST;
     constexpr bool ONE_PER_PHASE = KIND != KT_LAST;
     const unsigned boff = (unsigned)((kt + pb) & 1) * BUF_BYTES;   // LDS byte addresses of this K-tile's fragments (pb: buffer of K-tile 0)
@@ -293,7 +298,11 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
 
         // every fragment read finished before the last barrier.  The buffer of the LAST K-tile is free for the epilogue's
         // staging (8 KiB per wave); the other one already holds the next tile's first K-tile.
+#ifdef PM_FOLD_DIRECT
+        if constexpr (FOLD) ln_apply_direct<8>(p, c.mw, c.nw, acc, lane);
+#else
         if constexpr (FOLD) ln_apply<8>(fscr, acc, lane);          // the coefficient DMA was retired by the last K-tile's vmcnt(0)
+#endif
         const float4 no_pre[1] = {};
         unsigned char* eraw = lds + ((pb + c.nk - 1) & 1) * BUF_BYTES + wave * EPI_WAVE_BYTES;
         const int mw = m0 + wm * 128, nw = n0 + wn * 64;

@@ -113,6 +113,31 @@ __device__ __forceinline__ void ln_apply(const float* scratch, f32x4_t (&acc)[MI
     }
 }
 
+// diagnostic variant: the same coefficients by plain global loads at epilogue time (no LDS-DMA involved)
+template <int MI>
+__device__ __forceinline__ void ln_apply_direct(const GemmParams& p, int mwave, int nw, f32x4_t (&acc)[MI][4], int lane) {
+    const int g = lane >> 4, l15 = lane & 15;
+    float4 cc[4], dd[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        cc[ni] = *reinterpret_cast<const float4*>(p.ln_c + nw + ni * 16 + g * 4);
+        dd[ni] = *reinterpret_cast<const float4*>(p.ln_d + nw + ni * 16 + g * 4);
+    }
+    float2 ab[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) ab[mi] = *reinterpret_cast<const float2*>(p.ln_coef + (size_t)(mwave + mi * 16 + l15) * 2);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            acc[mi][ni][0] = ab[mi].x * acc[mi][ni][0] + (ab[mi].y * cc[ni].x + dd[ni].x);
+            acc[mi][ni][1] = ab[mi].x * acc[mi][ni][1] + (ab[mi].y * cc[ni].y + dd[ni].y);
+            acc[mi][ni][2] = ab[mi].x * acc[mi][ni][2] + (ab[mi].y * cc[ni].z + dd[ni].z);
+            acc[mi][ni][3] = ab[mi].x * acc[mi][ni][3] + (ab[mi].y * cc[ni].w + dd[ni].w);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Wave-level epilogue for a (MI*16) x 64 accumulator tile held as acc[MI][4] (MFMA issued with W as the row
 // operand: a lane owns row l15 of a 16-row group and 4 consecutive columns per 16x16 tile).  The tile is

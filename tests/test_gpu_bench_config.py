@@ -38,14 +38,8 @@ def test_bf16_one_step_against_fp32_verify_full_size(pipe512):
     pipe = pipe512
     _, d = load_golden("full_stage2.npz")
     ids0 = t(d["ids0"].astype(np.int64))
-    # the golden image plus seven with other random 60 % of the positions masked: top-1 agreement is a rate, and over one
-    # image's 1024 rows it moves by +-0.5 % between equally accurate arithmetic arrangements (tools/fold_accuracy_probe.py)
-    g = torch.Generator().manual_seed(7)
-    more = torch.randint(0, 8192, (7, 1024), generator=g)
-    more[torch.rand(7, 1024, generator=g) < 0.6] = pipe.mask_token_id
-    ids8 = torch.cat([ids0, more.to(dev())])
-    tok = pipe.ids2tokens(ids8)
-    l32 = torch.cat([pipe.tokens2logits(tok[i:i + 4], None) for i in (0, 4)])
+    tok = pipe.ids2tokens(ids0)
+    l32 = pipe.tokens2logits(tok, None)
     pipe.set_compute_dtype(torch.bfloat16)
     try:
         l16 = pipe.tokens2logits(tok, None)
@@ -64,10 +58,7 @@ def test_bf16_one_step_against_fp32_verify_full_size(pipe512):
           f"row cosine min {float(cos.min()):.6f} top-1 agreement {agree:.4f} "
           f"img mean abs dev {float((img16 - img32).abs().mean()):.5f} ids agreement {float((ids16 == ids32).float().mean()):.4f}")
     assert float(err.max()) < BF16_LOGIT_MAXERR and float(err.mean()) < BF16_LOGIT_MEANERR
-    # agreement over these 8 images (60 % of the positions masked: small top-2 gaps): 0.972 with the fp32 residual stream of
-    # rounds 1-2, with the bf16 hi/lo stream, and with the LayerNorm folded alike (tools/fold_accuracy_probe.py: 310 / 296 / 290
-    # flips of 16 384 on other inputs); the single golden image alone gave 0.990 / 0.9795 (10 / 21 flips of 1024): sample noise
-    assert float(cos.min()) > BF16_ROW_COSINE and agree >= 0.97
+    assert float(cos.min()) > BF16_ROW_COSINE and agree >= 0.98
     # a flip needs the two candidates closer than the two errors combined
     assert bool((gap[flips] < 2 * BF16_LOGIT_MAXERR).all())
     # and with this error level at most the rows whose gap is inside the noise may flip
@@ -219,60 +210,49 @@ def test_configs_4_and_5_graph_and_lanes_bit_identical_to_eager(name, B, T, L):
         torch.cuda.empty_cache()
 
 
-def pipe_fp32_logits(pipe, tok):
-    """fp32-verify logits of a pipeline that is currently in bf16 mode"""
-    pipe.set_compute_dtype(torch.float32)
-    try:
-        return pipe.tokens2logits(tok, None)
-    finally:
-        pipe.set_compute_dtype(torch.bfloat16)
-
-
-def test_layernorm_fold_against_the_separate_kernel_full_size(pipe512, monkeypatch):
-    """bf16 mode folds every LayerNorm into the GEMM that consumes it wherever the 256x256 kernel serves the shape (default);
-    PMHIP_LN_UNFOLD=1 runs pmhip_layernorm_hilo + the plain GEMMs instead.  Same maths up to bf16 rounding of the raw row
-    instead of the normalised row: both must sit equally close to the fp32-verify logits, the fold must remove the
-    LayerNorm-family launches of the full-row passes, and the decode loop must be bit-identical between the graph / lanes
-    path and the eager single stream in either setting."""
+def test_hilo_stream_and_layernorm_fold_full_size(pipe512, monkeypatch):
+    """PMHIP_HILO=1 (opt-in): bf16 mode keeps the residual stream as a bf16 hi/lo pair and folds every LayerNorm into the GEMM
+    that consumes it (PMHIP_LN_UNFOLD=1: the pair, but pmhip_layernorm_hilo + plain GEMMs).  Against the default fp32 stream:
+    equally close to the fp32-verify logits, no more top-1 flips, fewer bytes through the LayerNorm family, batch-invariant,
+    and the graph replay bit-identical to the eager loop on one stream.  (Concurrent lanes are NOT asserted here: that is
+    where the rare mismatch that keeps this path opt-in shows up -- tools/generate_race_stress.py)"""
     from paintmind_amd import ops
     pipe = pipe512
     _, d = load_golden("full_stage2.npz")
-    ids0 = t(np.repeat(d["ids0"].astype(np.int64), 16, axis=0))            # 16 images: every consumer GEMM is fold-eligible
+    ids0 = t(np.repeat(d["ids0"].astype(np.int64), 16, axis=0))            # 16 images
     tok = pipe.ids2tokens(ids0)
     l32 = pipe.tokens2logits(tok[:1], None)
+    g = torch.Generator().manual_seed(11)
+    ids8 = torch.randint(0, 8192, (8, 1024), generator=g)
+    ids8[torch.rand(8, 1024, generator=g) < 0.5] = pipe.mask_token_id
+    tok8 = pipe.ids2tokens(ids8.to(dev()))
+    l32_8 = torch.cat([pipe.tokens2logits(tok8[i:i + 4], None) for i in (0, 4)])
     pipe.set_compute_dtype(torch.bfloat16)
     try:
-        res = {}
-        for unfold in ("1", "0"):
-            monkeypatch.setenv("PMHIP_LN_UNFOLD", unfold)
-            res[unfold] = pipe.tokens2logits(tok, None)
+        res, ln, flips = {}, {}, {}
+        for mode, env in (("f32", {}), ("unfold", {"PMHIP_HILO": "1", "PMHIP_LN_UNFOLD": "1"}), ("fold", {"PMHIP_HILO": "1", "PMHIP_LN_UNFOLD": "0"})):
+            monkeypatch.delenv("PMHIP_HILO", raising=False)
+            monkeypatch.delenv("PMHIP_LN_UNFOLD", raising=False)
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            res[mode] = pipe.tokens2logits(tok, None)
             ops.timing_reset(); ops.timing_enable(True)
             pipe.tokens2logits(tok, None)
             torch.cuda.synchronize(); ops.timing_enable(False)
-            res["ln" + unfold] = ops.timing_get("layernorm")
-            assert torch.equal(res[unfold][:1], res[unfold][7:8])          # batch-invariant
+            ln[mode] = ops.timing_get("layernorm")
+            assert torch.equal(res[mode][:1], res[mode][7:8])              # batch-invariant
+            assert torch.equal(pipe.tokens2logits(tok[:3], None), res[mode][:3])   # ... also across batch sizes (fold decision)
+            flips[mode] = int((pipe.tokens2logits(tok8, None).argmax(-1) != l32_8.argmax(-1)).sum())
             flags = [True] * 4
             a = pipe.generate_ids(None, 16, 4, 1.0, 5, flags, seed=3, use_graph=False, streams=1)
             for _ in range(3):
-                b = pipe.generate_ids(None, 16, 4, 1.0, 5, flags, seed=3, use_graph=True, streams=2)
-                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-        (n_plain, ms_plain), (n_fold, ms_fold) = res["ln1"], res["ln0"]
-        assert n_plain == 37 and n_fold == 37, (n_plain, n_fold)           # 12 layers x 3 + the final norm: one row pass each way
-        e_plain, e_fold = float((res["1"][:1] - l32).abs().max()), float((res["0"][:1] - l32).abs().max())
-        # the fold must not cost top-1 agreement with fp32-verify either: flips counted on 8 different images for both routes
-        g = torch.Generator().manual_seed(11)
-        ids8 = torch.randint(0, 8192, (8, 1024), generator=g)
-        ids8[torch.rand(8, 1024, generator=g) < 0.5] = pipe.mask_token_id
-        tok8 = pipe.ids2tokens(ids8.to(dev()))
-        l32_8 = pipe_fp32_logits(pipe, tok8)
-        flips = {}
-        for unfold in ("1", "0"):
-            monkeypatch.setenv("PMHIP_LN_UNFOLD", unfold)
-            flips[unfold] = int((pipe.tokens2logits(tok8, None).argmax(-1) != l32_8.argmax(-1)).sum())
-        print(f"top-1 flips vs fp32 on 8192 rows: unfolded {flips['1']} folded {flips['0']}")
-        assert flips["0"] <= 1.2 * flips["1"] + 10
-        print(f"logits max err vs fp32: unfolded {e_plain:.5f} folded {e_fold:.5f}; LayerNorm-family time {ms_plain:.3f} -> {ms_fold:.3f} ms")
-        assert e_fold < BF16_LOGIT_MAXERR and e_fold < 2.0 * e_plain + 1e-3
-        assert ms_fold < 0.8 * ms_plain                                    # the coefficient pass reads 2 of the 6 bytes per element (launch-bound at this size)
+                b = pipe.generate_ids(None, 16, 4, 1.0, 5, flags, seed=3, use_graph=True, streams=1)
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), mode
+        errs = {m: float((res[m][:1] - l32).abs().max()) for m in res}
+        print(f"logits max err vs fp32: {errs}; top-1 flips on 8192 rows: {flips}; LayerNorm-family (launches, ms): {ln}")
+        assert all(n_ == 37 for n_, _ in ln.values())                      # 12 layers x 3 + the final norm: one row pass each way
+        assert errs["fold"] < BF16_LOGIT_MAXERR and errs["fold"] < 2.0 * errs["f32"] + 1e-3 and errs["unfold"] < 2.0 * errs["f32"] + 1e-3
+        assert flips["fold"] <= 1.2 * flips["f32"] + 10 and flips["unfold"] <= 1.2 * flips["f32"] + 10
+        assert ln["fold"][1] < 0.8 * ln["f32"][1]                          # the coefficient pass reads 2 of the 6 bytes per element
     finally:
         pipe.set_compute_dtype(torch.float32)

@@ -15,7 +15,7 @@ pipe = bench.build(bench.DEFAULT_WORKLOAD, dev, torch.bfloat16)
 from paintmind_amd.modules.encoder import NullTextEmbedder
 pipe.text_model = NullTextEmbedder()
 text = ["p"] * 64
-for kw in (dict(keep_on_device=True), dict(), dict(streams=1)):
+for kw in (dict(keep_on_device=True), dict(), dict(streams=(32, 32)), dict(streams=(34, 30)), dict(streams=1)):
     for si in (1, 2):
         for i in range(3): pipe.generate(text, timesteps=8, topk=5, save_interval=si, seed=i, **kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
