@@ -69,7 +69,8 @@ int pmhip_gemm_heads(int dtype, const void* A, int lda, const void* W, int ldw, 
                      int heads, int tokens, int tokens_pad, int nparts, const int* part_kinds_host,
                      void* const* part_outs_host, float q_scale, pmhip_stream stream);
 
-/* ---- bf16 mode: the residual stream as a bf16 PAIR, and the LayerNorm folded into the GEMM that consumes it
+/* ---- bf16 mode, OPT-IN at the model level (PMHIP_HILO=1; DESIGN.md section 4d says why it is not the default): the
+ * residual stream as a bf16 PAIR, and the LayerNorm folded into the GEMM that consumes it
  * (stage1/layers.py:54-58, stage2/transformer.py:44-49: x = f(LN(x)) + x, every projection preceded by a LayerNorm).
  * x = hi + lo with hi = bf16(x), lo = bf16(x - hi): two bf16 planes [M, D] -- the same 4 bytes per element as fp32 and, for a
  * stream built by adding bf16-GEMM outputs, the same accuracy (tools/residual_precision_probe.py: logits identical to the
