@@ -91,6 +91,33 @@ __device__ __forceinline__ void ln_coef_issue(const GemmParams& p, int mwave, in
     __builtin_amdgcn_global_load_lds((gbl_void*)(p.ln_d + nw + lane), (lds_void*)(scratch + 320), 4, 0, 0);
 }
 
+// HARDWARE HAZARD (gfx950, tools/hwtests/pkfma_mfma.hip): a v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 whose LOW half
+// takes SRC1 from the HIGH register of its pair (`op_sel:[_,1,_]`, what hipcc emits to broadcast a scalar that sits in an odd
+// register) loses that operand in lanes 48-63 -- the product comes out as zero -- when the OTHER wave of the SIMD issues the first
+// bf16 MFMA of a block in the same cycles.  The lead waves of gemm256 normalise exactly while their lag waves start the tile's last
+// MFMA block, and hipcc compiled the plain C++ of this function to 64 such instructions: one accumulator register wrong in one
+// 16-lane group once per ~10^9 wave-tiles.  The per-row coefficients are therefore splatted into REAL register pairs through
+// opaque moves and the packed FMAs are written without operand selects; tests/test_isa_hazards.py refuses any build that
+// contains the vulnerable form.  The arithmetic (two fused multiply-adds per element) and its rounding are unchanged.
+typedef float pk2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2_t pk_splat(float v) {
+    float lo, hi;
+    asm("v_mov_b32 %0, %1" : "=v"(lo) : "v"(v));
+    asm("v_mov_b32 %0, %1" : "=v"(hi) : "v"(v));
+    return pk2_t{lo, hi};
+}
+__device__ __forceinline__ pk2_t pk_fma_plain(pk2_t a, pk2_t b, pk2_t c) {
+    pk2_t d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// acc[0..3] = x * acc[0..3] + (y * c[0..3] + d[0..3]) for one 16x16 tile slice of a lane; x | y are splatted pairs
+__device__ __forceinline__ void ln_apply4(f32x4_t& acc, pk2_t xx, pk2_t yy, const float4& c, const float4& d) {
+    const pk2_t t0 = pk_fma_plain(pk2_t{c.x, c.y}, yy, pk2_t{d.x, d.y}), t1 = pk_fma_plain(pk2_t{c.z, c.w}, yy, pk2_t{d.z, d.w});
+    const pk2_t o0 = pk_fma_plain(xx, pk2_t{acc[0], acc[1]}, t0), o1 = pk_fma_plain(xx, pk2_t{acc[2], acc[3]}, t1);
+    acc[0] = o0[0]; acc[1] = o0[1]; acc[2] = o1[0]; acc[3] = o1[1];
+}
+
 template <int MI>
 __device__ __forceinline__ void ln_apply(const float* scratch, f32x4_t (&acc)[MI][4], int lane) {
     const int g = lane >> 4, l15 = lane & 15;
@@ -103,13 +130,9 @@ __device__ __forceinline__ void ln_apply(const float* scratch, f32x4_t (&acc)[MI
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const float2 ab = *reinterpret_cast<const float2*>(scratch + (mi * 16 + l15) * 2);      // row mwave + mi*16 + l15
+        const pk2_t xx = pk_splat(ab.x), yy = pk_splat(ab.y);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            acc[mi][ni][0] = ab.x * acc[mi][ni][0] + (ab.y * cc[ni].x + dd[ni].x);
-            acc[mi][ni][1] = ab.x * acc[mi][ni][1] + (ab.y * cc[ni].y + dd[ni].y);
-            acc[mi][ni][2] = ab.x * acc[mi][ni][2] + (ab.y * cc[ni].z + dd[ni].z);
-            acc[mi][ni][3] = ab.x * acc[mi][ni][3] + (ab.y * cc[ni].w + dd[ni].w);
-        }
+        for (int ni = 0; ni < 4; ++ni) ln_apply4(acc[mi][ni], xx, yy, cc[ni], dd[ni]);
     }
 }
 
@@ -128,13 +151,9 @@ __device__ __forceinline__ void ln_apply_direct(const GemmParams& p, int mwave, 
     for (int mi = 0; mi < MI; ++mi) ab[mi] = *reinterpret_cast<const float2*>(p.ln_coef + (size_t)(mwave + mi * 16 + l15) * 2);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+        const pk2_t xx = pk_splat(ab[mi].x), yy = pk_splat(ab[mi].y);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            acc[mi][ni][0] = ab[mi].x * acc[mi][ni][0] + (ab[mi].y * cc[ni].x + dd[ni].x);
-            acc[mi][ni][1] = ab[mi].x * acc[mi][ni][1] + (ab[mi].y * cc[ni].y + dd[ni].y);
-            acc[mi][ni][2] = ab[mi].x * acc[mi][ni][2] + (ab[mi].y * cc[ni].z + dd[ni].z);
-            acc[mi][ni][3] = ab[mi].x * acc[mi][ni][3] + (ab[mi].y * cc[ni].w + dd[ni].w);
-        }
+        for (int ni = 0; ni < 4; ++ni) ln_apply4(acc[mi][ni], xx, yy, cc[ni], dd[ni]);
     }
 }
 
