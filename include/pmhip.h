@@ -69,7 +69,7 @@ int pmhip_gemm_heads(int dtype, const void* A, int lda, const void* W, int ldw, 
                      int heads, int tokens, int tokens_pad, int nparts, const int* part_kinds_host,
                      void* const* part_outs_host, float q_scale, pmhip_stream stream);
 
-/* ---- bf16 mode, OPT-IN at the model level (PMHIP_HILO=1; DESIGN.md section 4d says why it is not the default): the
+/* ---- bf16 mode (the model-level default since round 3; PMHIP_HILO=0 restores the fp32 stream; DESIGN.md sections 4d, 4e): the
  * residual stream as a bf16 PAIR, and the LayerNorm folded into the GEMM that consumes it
  * (stage1/layers.py:54-58, stage2/transformer.py:44-49: x = f(LN(x)) + x, every projection preceded by a LayerNorm).
  * x = hi + lo with hi = bf16(x), lo = bf16(x - hi): two bf16 planes [M, D] -- the same 4 bytes per element as fp32 and, for a

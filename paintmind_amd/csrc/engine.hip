@@ -173,15 +173,14 @@ int check_dim_head(const char* who, const pmhip_tower_cfg& tc) {
     return PMHIP_OK;
 }
 
-// The bf16 hi/lo residual stream + folded LayerNorm is OPT-IN (PMHIP_HILO=1, read on every forward): it is 1.3 % faster on
-// the default workload (same box: 476.5 vs 470.6 images/s) and as accurate, but with concurrent lanes 3-11 of 1800
-// generate() calls of the text-conditioned configurations were not bit-identical to the single-stream result
-// (tools/generate_race_stress.py; never in 1800 calls with PMHIP_LN_UNFOLD=1 or with the fp32 stream).  One instance was
-// caught at operator level after 120 000 launches on three streams (tools/fold_race_stress.py): a folded logits GEMM with ONE
-// accumulator register wrong in one 16-lane group (16 rows x 1 column).  Not root-caused; DESIGN.md section 4d.
+// The bf16 hi/lo residual stream + folded LayerNorm is the DEFAULT of bf16 mode (PMHIP_HILO=0, read on every forward, restores
+// the fp32 stream + LayerNorm kernel of rounds 1-2): 1.3 % faster on the default workload (same box: 476.5 vs 470.6 images/s),
+// as accurate.  It was opt-in while 3-11 of 1800 generate() calls under concurrent lanes were not
+// bit-identical; that was a gfx950 packed-FP32 operand-select hazard in the folded epilogue, fixed in
+// gemm_common.h and gated by tests/test_isa_hazards.py.
 bool hilo_enabled() {
     const char* e = getenv("PMHIP_HILO");
-    return e && atoi(e) != 0;
+    return !(e && atoi(e) == 0);
 }
 
 bool ln_fold_enabled() {
