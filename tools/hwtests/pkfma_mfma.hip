@@ -7,7 +7,7 @@
 // and op_sel_hi:[0,1,1]) on fixed register inputs and compare every result bit for bit with the result of the same burst
 // computed while the whole workgroup was quiet; waves 4-7 (the siblings) either idle or run v_mfma_f32_16x16x32_bf16 blocks,
 // started by the same s_barrier as the burst.
-//   hipcc --offload-arch=gfx950 -O2 -o pkfma_mfma tools/hwtests/pkfma_mfma.hip && ./pkfma_mfma [seconds_per_mode]
+//   hipcc --offload-arch=gfx950 -O2 -o pkfma_mfma tools/hwtests/pkfma_mfma.hip && ./pkfma_mfma [seconds_per_mode] [quick]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -257,6 +257,7 @@ void run(const float* seed, Report* rep, double seconds, const char* what) {
 
 int main(int argc, char** argv) {
     const double seconds = argc > 1 ? atof(argv[1]) : 4.0;
+    const bool quick = argc > 2 && argv[2][0] == 'q';        // control, the hazard, the fix (tests/test_gpu_hazard_probe.py)
     const size_t n = (size_t)256 * 512 * 96;
     float* hs = (float*)malloc(n * 4);
     unsigned x = 12345u;
@@ -265,6 +266,16 @@ int main(int argc, char** argv) {
     hipMalloc(&seed, n * 4); hipMalloc(&rep, sizeof(Report));
     hipMemcpy(seed, hs, n * 4, hipMemcpyHostToDevice);
 #define RUN(AV, BV, DELAY, LDSRD, what) run<AV, BV, DELAY, LDSRD>(seed, rep, seconds, what)
+    if (quick) {
+        RUN(0, 0, 0, false, "CONTROL op_sel:[0,1,0] | siblings idle");
+        RUN(0, 1, 0, false, "HAZARD op_sel:[0,1,0] | setprio + 16 MFMA bf16");
+        RUN(0, 1, 2, false, "HAZARD op_sel:[0,1,0] | 32 cycles later: setprio + 16 MFMA bf16");
+        RUN(5, 1, 0, false, "FIX no op_sel | setprio + 16 MFMA bf16");
+        RUN(5, 1, 1, false, "FIX no op_sel | 16 cycles later: setprio + 16 MFMA bf16");
+        RUN(5, 1, 2, false, "FIX no op_sel | 32 cycles later: setprio + 16 MFMA bf16");
+        RUN(5, 1, 4, false, "FIX no op_sel | 64 cycles later: setprio + 16 MFMA bf16");
+        return 0;
+    }
     RUN(0, 0, 0, false, "pk_fma t0,t1,o0,o1 | siblings idle");
     RUN(0, 1, 0, false, "pk_fma t0,t1,o0,o1 | setprio + 16 MFMA bf16");
     RUN(0, 2, 0, false, "pk_fma t0,t1,o0,o1 | 16 MFMA bf16, no setprio");
