@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PMHIP_ABI_VERSION 6
+#define PMHIP_ABI_VERSION 7
 
 enum { PMHIP_OK = 0, PMHIP_EINVAL = 1, PMHIP_EHIP = 2, PMHIP_ENOMEM = 3, PMHIP_ESTATE = 4 };
 enum { PMHIP_F32 = 0, PMHIP_BF16 = 1 };
@@ -86,6 +86,12 @@ int pmhip_gemm_heads(int dtype, const void* A, int lda, const void* W, int ldw, 
 int pmhip_gemm_hilo(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
                     const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N,
                     int K, pmhip_stream stream);
+/* The same, and row_stats[M][N/64][2] = per row and per 64-column part (sum, sum of squares centred on the part's own mean) of
+ * the NEW hi plane, written by the epilogue (N a multiple of 64): the LayerNorm folded into the next GEMM then needs no pass
+ * over the plane -- pmhip_ln_coef_parts below instead of pmhip_ln_coef. */
+int pmhip_gemm_hilo_stats(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
+                          const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N,
+                          int K, float* row_stats, pmhip_stream stream);
 /* row operators on the pair (D a multiple of 4, <= 1024): LayerNorm of hi + lo -> f32 / bf16 (the unfolded path);
  * LayerNorm of an f32 row -> hi, lo; f32 -> hi, lo and back */
 int pmhip_layernorm_hilo(const void* x_hi, const void* x_lo, const float* gamma, const float* beta, float eps,
@@ -96,6 +102,9 @@ int pmhip_split_hilo(const float* x, void* out_hi, void* out_lo, int M, int D, p
 int pmhip_join_hilo(const void* x_hi, const void* x_lo, float* out, int M, int D, pmhip_stream stream);
 /* coef[M][2] = (rstd, -rstd * mean) of the rows of the hi plane (two-pass, like the LayerNorm kernel) */
 int pmhip_ln_coef(const void* x_hi, float eps, float* coef, int M, int D, pmhip_stream stream);
+/* the same coefficients from pmhip_gemm_hilo_stats' partial statistics (D = 64 * nparts <= 1024): Chan's combination in part
+ * order, deterministic; equal to pmhip_ln_coef to rounding (a few ulp of rstd) */
+int pmhip_ln_coef_parts(const float* row_stats, int nparts, float eps, float* coef, int M, pmhip_stream stream);
 
 typedef struct pmhip_lnfold {
     const float* coef;    /* [M][2]: (rstd, -rstd * mean) per row, from pmhip_ln_coef */

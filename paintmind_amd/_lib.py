@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpaintmind_hip.so")
 PMHIP_OK = 0
 F32, BF16 = 0, 1
 PART_Q, PART_K, PART_V = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 vp = C.c_void_p
 i32 = C.c_int
@@ -73,6 +73,8 @@ PROTOTYPES = {
     "pmhip_gemm_heads": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32),
                                C.POINTER(vp), f32, vp]),
     "pmhip_gemm_hilo": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "pmhip_gemm_hilo_stats": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "pmhip_ln_coef_parts": (i32, [vp, i32, f32, vp, i32, vp]),
     "pmhip_layernorm_hilo": (i32, [vp, vp, vp, vp, f32, vp, i32, i32, i32, vp]),
     "pmhip_layernorm_to_hilo": (i32, [vp, vp, vp, f32, vp, vp, i32, i32, vp]),
     "pmhip_split_hilo": (i32, [vp, vp, vp, i32, i32, vp]),

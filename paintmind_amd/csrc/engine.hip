@@ -149,6 +149,8 @@ struct TowerBufs {
     void* hid = nullptr;    // T [M, hidden_pad]
     float* split = nullptr; // dim_head != 64 only: f32 scratch of the plain head-split path [M, 3*inner]
     float* coef = nullptr;  // LayerNorm fold: per-row (rstd, -rstd * mean) of the hi plane
+    float* parts = nullptr; // ... and the partial row statistics the last residual GEMM left behind, [M, dim/64, 2]
+    bool parts_valid = false;   // parts describe the CURRENT hi plane (set by residual_gemm, see tower_coef)
     bool hilo = false;      // bf16 mode
     bool fold = false;      // hilo and folding not disabled (PMHIP_LN_UNFOLD=1 forces the separate LayerNorm kernel: A/B tests)
 };
@@ -183,6 +185,11 @@ bool hilo_enabled() {
     return !(e && atoi(e) == 0);
 }
 
+bool ln_stats_enabled() {
+    const char* e = getenv("PMHIP_LN_STATS");
+    return !(e && atoi(e) == 0);
+}
+
 bool ln_fold_enabled() {
     const char* e = getenv("PMHIP_LN_UNFOLD");
     return !(e && atoi(e) != 0);
@@ -208,6 +215,8 @@ int alloc_tower(Workspace& ws, const char* tag, int dtype, const pmhip_tower_cfg
     WS(ws, (t + ".attn").c_str(), M * inner * es, b.attn);
     WS(ws, (t + ".hid").c_str(), M * tc.hidden_pad * es, b.hid);
     WS(ws, (t + ".coef").c_str(), M * 2 * 4, b.coef);
+    WS(ws, (t + ".parts").c_str(), M * (size_t)round_up(tc.dim, 64) / 64 * 2 * 4, b.parts);
+    b.parts_valid = false;
     b.split = nullptr;
     if (dh != 64) WS(ws, (t + ".split").c_str(), M * 3 * inner * 4, b.split);
     b.fold = b.hilo && dh == 64 && ln_fold_enabled();
@@ -224,8 +233,21 @@ ResSrc res_self(const TowerBufs& b, int dim) {
 // residual GEMM x = A . W^T + bias + addend, written to the tower's residual stream (in place when the addend is the stream)
 int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W, int ldw, const float* bias, const ResSrc& r,
                   int M, int N, int K, hipStream_t s) {
-    if (b.hilo) return pmhip_gemm_hilo(A, lda, W, ldw, bias, r.hi, r.lo, r.ld, r.rows, b.xh, b.xl, N, M, N, K, s);
+    if (b.hilo) {
+        // with the LayerNorm folded into the consumers the producer's epilogue also leaves the row statistics of the new hi plane
+        // (16 bytes per 64 columns): the coefficient pass over the plane (pmhip_ln_coef, 14 us per launch at the bench shape)
+        // becomes a combination of 8-16 partials per row.  PMHIP_LN_STATS=0: the pass (A/B).
+        b.parts_valid = b.fold && N % 64 == 0 && ln_stats_enabled();
+        if (b.parts_valid) return pmhip_gemm_hilo_stats(A, lda, W, ldw, bias, r.hi, r.lo, r.ld, r.rows, b.xh, b.xl, N, M, N, K, b.parts, s);
+        return pmhip_gemm_hilo(A, lda, W, ldw, bias, r.hi, r.lo, r.ld, r.rows, b.xh, b.xl, N, M, N, K, s);
+    }
     return pmhip_gemm(dtype, A, lda, W, ldw, bias, r.f32, r.ld, r.rows, b.x, N, PMHIP_F32, M, N, K, s);
+}
+
+// (rstd, -rstd * mean) of the rows of the current hi plane into b.coef
+int tower_coef(TowerBufs& b, int M, int dim, hipStream_t s) {
+    if (b.parts_valid) return pmhip_ln_coef_parts(b.parts, dim / 64, 1e-5f, b.coef, M, s);
+    return pmhip_ln_coef(b.xh, 1e-5f, b.coef, M, dim, s);
 }
 
 // LN(x) of the tower's residual stream into b.y (the unfolded path)
@@ -244,7 +266,7 @@ int ln_heads(int dtype, TowerBufs& b, const float* g, const float* be, const voi
              int M, int dim, int heads, int dh, int tokens, int Np, int nparts, const int* kinds, void* const* outs, float q_scale,
              hipStream_t s) {
     if (b.fold && Wf && fold_shape_ok(tokens, nparts * heads * 64, dim)) {
-        PM_TRY(pmhip_ln_coef(b.xh, 1e-5f, b.coef, M, dim, s));
+        PM_TRY(tower_coef(b, M, dim, s));
         const pmhip_lnfold ln{b.coef, fc, fd};
         return pmhip_gemm_heads_ln(dtype, b.xh, dim, Wf, dim, M, dim, heads, tokens, Np, nparts, kinds, outs, q_scale, &ln, s);
     }
@@ -290,7 +312,7 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
 
     // x = ffnet(norm(x)) + x
     if (b.fold && L.w12p_f && fold_shape_ok(tokens, 2 * tc.hidden_pad, dim)) {
-        PM_TRY(pmhip_ln_coef(b.xh, 1e-5f, b.coef, M, dim, s));
+        PM_TRY(tower_coef(b, M, dim, s));
         const pmhip_lnfold ln{b.coef, L.w12_c, L.w12_d};
         PM_TRY(pmhip_gemm_swiglu_ln(dtype, b.xh, dim, L.w12p_f, L.b12p, b.hid, tc.hidden_pad, M, tc.hidden_pad, dim, &ln, s));
     } else {
@@ -615,7 +637,7 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s) {
     for (int l = 0; l < c.tower.depth; ++l)
         PM_TRY(layer_forward(h->dtype, h->layers[l], c.tower, tb, B, c.tokens, true, &h->cross[l], s));
     if (tb.fold && h->w.logits_wf && fold_shape_ok(c.tokens, c.n_embed, dim)) {
-        PM_TRY(pmhip_ln_coef(tb.xh, 1e-5f, tb.coef, M, dim, s));
+        PM_TRY(tower_coef(tb, M, dim, s));
         const pmhip_lnfold ln{tb.coef, h->w.logits_c, h->w.logits_d};                    // the final norm folded into to_logits
         return pmhip_gemm_ln(h->dtype, tb.xh, dim, h->w.logits_wf, dim, h->w.logits_b, logits, c.n_embed, PMHIP_F32, M, c.n_embed, dim,
                              &ln, s);
@@ -777,7 +799,7 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
 
     std::string key = "B" + std::to_string(B) + "T" + std::to_string(T) + "k" + std::to_string(topk) + "L" +
                       std::to_string(context ? L : 0) + "v" + std::to_string(vq ? vq->uid : 0) + "f" +
-                      std::to_string((hilo_enabled() ? 2 : 0) + (ln_fold_enabled() ? 1 : 0)) + "d";
+                      std::to_string((hilo_enabled() ? 2 : 0) + (ln_fold_enabled() ? 1 : 0) + (ln_stats_enabled() ? 4 : 0)) + "d";
     for (int t = 0; t < T; ++t) key += (decode_host && decode_host[t]) ? '1' : '0';
     GraphEntry& ge = s2->graphs[key];
 

@@ -225,22 +225,38 @@ extern "C" int pmhip_gemm(int dtype, const void* A, int lda, const void* W, int 
     return gemm_impl(dtype, A, lda, W, ldw, bias, residual, ldr, res_rows, out, ldo, out_dtype, M, N, K, nullptr, stream);
 }
 
-// bf16 hi/lo residual stream: (hi, lo) <- split(A . W^T + bias + (res_hi + res_lo)); in place when the planes coincide
-extern "C" int pmhip_gemm_hilo(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
-                               const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N, int K,
-                               pmhip_stream stream) {
+// bf16 hi/lo residual stream: (hi, lo) <- split(A . W^T + bias + (res_hi + res_lo)); in place when the planes coincide.
+// row_stats (optional): per-row partial statistics of the new hi plane, [M][N/64][2] (gemm_common.h)
+static int gemm_hilo_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
+                          const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N, int K,
+                          float* row_stats, pmhip_stream stream) {
     GemmParams p{};
     p.A = A; p.W = W; p.bias = bias; p.residual = reinterpret_cast<const float*>(res_hi); p.out = out_hi;
     p.res_lo = reinterpret_cast<const bf16_t*>(res_lo); p.out_lo = reinterpret_cast<bf16_t*>(out_lo);
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.res_rows = res_rows > 0 ? res_rows : M; p.ldo = ldo;
     p.M = M; p.N = N; p.K = K;
+    p.row_stats = row_stats;
     PM_TRY(check_common(p, PMHIP_BF16));
     PM_REQUIRE(res_hi && res_lo && out_hi && out_lo, "gemm_hilo: null plane");
     PM_REQUIRE(N % 8 == 0 && ldo % 8 == 0 && ldr % 8 == 0, "gemm_hilo: N=%d, ldo=%d, ldr=%d must be multiples of 8", N, ldo, ldr);
+    PM_REQUIRE(!row_stats || N % 64 == 0, "gemm_hilo_stats: N=%d must be a multiple of 64", N);
     hipStream_t s = (hipStream_t)stream;
     if (use2b(p, PMHIP_BF16, EPI_STD, PMHIP_BF16)) return pm_gemm2b_launch(p, EPI_STD, PMHIP_BF16, s);
     if (use256(p, PMHIP_BF16, EPI_STD, PMHIP_BF16)) return pm_gemm256_launch(p, EPI_STD, PMHIP_BF16, s);
     return launch<bf16_t, EPI_STD, bf16_t>(p, s);
+}
+
+extern "C" int pmhip_gemm_hilo(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
+                               const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N, int K,
+                               pmhip_stream stream) {
+    return gemm_hilo_impl(A, lda, W, ldw, bias, res_hi, res_lo, ldr, res_rows, out_hi, out_lo, ldo, M, N, K, nullptr, stream);
+}
+
+extern "C" int pmhip_gemm_hilo_stats(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
+                                     const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N,
+                                     int K, float* row_stats, pmhip_stream stream) {
+    PM_REQUIRE(row_stats, "gemm_hilo_stats: null statistics buffer");
+    return gemm_hilo_impl(A, lda, W, ldw, bias, res_hi, res_lo, ldr, res_rows, out_hi, out_lo, ldo, M, N, K, row_stats, stream);
 }
 
 extern "C" int pmhip_gemm_ln(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldo,

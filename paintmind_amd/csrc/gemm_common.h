@@ -29,6 +29,11 @@ struct GemmParams {
     // stride ldo).  The hi plane alone is what the next GEMM consumes (LayerNorm folded into it), so the stream costs the
     // same 4 + 4 bytes per element as fp32 but needs no separate normalisation pass.
     const bf16_t* res_lo; bf16_t* out_lo;
+    // ... and, optionally, the row statistics of the NEW hi plane, so that the LayerNorm folded into the next GEMM needs no pass
+    // over the plane (pmhip_ln_coef reads 2 bytes per element: 14 us per launch at the bench shape, 4.4 % of GPU time):
+    // row_stats[m][N/64][2] = (sum, centred sum of squares) of the 64 columns a wave owns; pmhip_ln_coef_parts combines them
+    // (Chan's update, fixed order).  Needs N % 64 == 0.
+    float* row_stats;
     // LayerNorm fold, consumer side (256x256 kernel): A is the RAW bf16 row (the hi plane), W carries gamma, and the epilogue
     // applies out = rstd * acc - rstd * mean * c[n] + d[n]
     const float* ln_coef;                          // [M][2]: (rstd, -rstd * mean) per row, from pmhip_ln_coef
@@ -485,6 +490,20 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                         }
                         nt_store16(reinterpret_cast<bf16_t*>(p.out) + (size_t)mm * p.ldo + ncol, make_uint4(oh[0], oh[1], oh[2], oh[3]));
                         nt_store16(p.out_lo + (size_t)mm * p.ldo + ncol, make_uint4(ol[0], ol[1], ol[2], ol[3]));
+                        if (p.row_stats) {                          // wave-uniform.  The 8 lanes of a row hold its 64 hi values of this wave
+                            float hv[8];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { hv[2 * j] = __uint_as_float(oh[j] << 16); hv[2 * j + 1] = __uint_as_float(oh[j] & 0xffff0000u); }
+                            float sm = ((hv[0] + hv[1]) + (hv[2] + hv[3])) + ((hv[4] + hv[5]) + (hv[6] + hv[7]));
+                            sm += dpp_mov<0xB1>(sm); sm += dpp_mov<0x4E>(sm); sm += dpp_mov<0x141>(sm);
+                            const float pm = sm * (1.0f / 64.0f);
+                            float q2 = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { const float a = hv[j] - pm; q2 = fmaf(a, a, q2); }
+                            q2 += dpp_mov<0xB1>(q2); q2 += dpp_mov<0x4E>(q2); q2 += dpp_mov<0x141>(q2);
+                            if ((lane & 7) == 0)
+                                *reinterpret_cast<float2*>(p.row_stats + ((size_t)mm * (p.N >> 6) + (nw >> 6)) * 2) = make_float2(sm, q2);
+                        }
                         continue;
                     }
                     if constexpr (sizeof(OutT) == 4 && RES != 0) {

@@ -336,6 +336,29 @@ __global__ __launch_bounds__(THREADS) void ln_coef_kernel(const bf16_t* __restri
     }
 }
 
+// The same coefficients from the partial statistics a hi/lo producer GEMM left behind (gemm_common.h: per row and per 64-column
+// part the sum and the sum of squares centred on the part's own mean): Chan's combination, eight lanes per row.
+// 16 bytes per part and row instead of a pass over the plane.
+__global__ __launch_bounds__(THREADS) void ln_coef_parts_kernel(const float2* __restrict__ parts, int nparts, float eps,
+                                                                float2* __restrict__ coef, int M) {
+    // 8 lanes per row: lane j takes parts j and j + 8 (a wave reads 8 rows = 512 or 1024 contiguous bytes), DPP sums over the
+    // 8 lanes in a fixed order
+    const int t = blockIdx.x * THREADS + threadIdx.x;
+    const int row = t >> 3, j = t & 7;
+    const bool live = row < M;
+    const float2* pr = parts + (size_t)(live ? row : 0) * nparts;
+    const float2 p0 = (live && j < nparts) ? pr[j] : make_float2(0.f, 0.f);
+    const float2 p1 = (live && j + 8 < nparts) ? pr[j + 8] : make_float2(0.f, 0.f);
+    float s = p0.x + p1.x;
+    s += dpp_mov<0xB1>(s); s += dpp_mov<0x4E>(s); s += dpp_mov<0x141>(s);
+    const float mean = s / (float)(nparts * 64);
+    const float d0 = p0.x * (1.0f / 64.0f) - mean, d1 = p1.x * (1.0f / 64.0f) - mean;
+    float m2 = (j < nparts ? p0.y + 64.0f * d0 * d0 : 0.f) + (j + 8 < nparts ? p1.y + 64.0f * d1 * d1 : 0.f);
+    m2 += dpp_mov<0xB1>(m2); m2 += dpp_mov<0x4E>(m2); m2 += dpp_mov<0x141>(m2);
+    const float rstd = 1.0f / sqrtf(m2 / (float)(nparts * 64) + eps);
+    if (live && j == 0) coef[row] = make_float2(rstd, -rstd * mean);
+}
+
 template <bool IN_HILO, int MODE>
 static int launch_hilo(const float* x, const void* xh, const void* xl, const float* g, const float* b, float eps, void* out, void* out_lo,
                        int M, int D, hipStream_t s) {
@@ -385,6 +408,17 @@ extern "C" int pmhip_ln_coef(const void* x_hi, float eps, float* coef, int M, in
     constexpr int RPW = 4;
     hipLaunchKernelGGL((ln_coef_kernel<RPW>), dim3(ceil_div(M, (THREADS / 64) * RPW)), dim3(THREADS), 0, s,
                        reinterpret_cast<const bf16_t*>(x_hi), eps, reinterpret_cast<float2*>(coef), M, D);
+    PM_HIP(hipGetLastError());
+    return PMHIP_OK;
+}
+
+extern "C" int pmhip_ln_coef_parts(const float* row_stats, int nparts, float eps, float* coef, int M, pmhip_stream stream) {
+    PM_REQUIRE(row_stats && coef, "ln_coef_parts: null pointer");
+    PM_REQUIRE(M > 0 && nparts > 0 && nparts <= 16, "ln_coef_parts: nparts=%d must be in [1,16] (D = 64 * nparts <= 1024)", nparts);
+    hipStream_t s = (hipStream_t)stream;
+    PmTimer tm(FAM_LAYERNORM, s);
+    hipLaunchKernelGGL(ln_coef_parts_kernel, dim3(ceil_div(M * 8, THREADS)), dim3(THREADS), 0, s,
+                       reinterpret_cast<const float2*>(row_stats), nparts, eps, reinterpret_cast<float2*>(coef), M);
     PM_HIP(hipGetLastError());
     return PMHIP_OK;
 }

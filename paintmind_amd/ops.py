@@ -137,8 +137,9 @@ def join_hilo(hi, lo):
     return out
 
 
-def gemm_hilo(a, w, res_hi, res_lo, bias=None, res_rows=0):
-    """(hi, lo) = split(a @ w^T + bias + (res_hi + res_lo)[m % res_rows]); bf16 operands"""
+def gemm_hilo(a, w, res_hi, res_lo, bias=None, res_rows=0, stats=False):
+    """(hi, lo) = split(a @ w^T + bias + (res_hi + res_lo)[m % res_rows]); bf16 operands.
+    stats=True: also the per-row partial statistics [M, N/64, 2] of the new hi plane (for ln_coef_parts)."""
     dev = _dev(a, w, res_hi, res_lo)
     lib = _lib.load()
     M, K = a.shape
@@ -146,9 +147,25 @@ def gemm_hilo(a, w, res_hi, res_lo, bias=None, res_rows=0):
     hi = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     lo = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     with torch.cuda.device(dev):
+        if stats:
+            parts = torch.full((M, N // 64, 2), float("nan"), device=dev, dtype=torch.float32)
+            check(lib.pmhip_gemm_hilo_stats(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(res_hi), _p(res_lo), res_hi.stride(0),
+                                            int(res_rows), _p(hi), _p(lo), N, M, N, K, _p(parts), stream_ptr(dev)), "pmhip_gemm_hilo_stats")
+            return hi, lo, parts
         check(lib.pmhip_gemm_hilo(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(res_hi), _p(res_lo), res_hi.stride(0),
                                   int(res_rows), _p(hi), _p(lo), N, M, N, K, stream_ptr(dev)), "pmhip_gemm_hilo")
     return hi, lo
+
+
+def ln_coef_parts(parts, eps=1e-5):
+    """per-row (rstd, -rstd * mean) from gemm_hilo(..., stats=True)'s partial statistics -> f32 [M,2]"""
+    dev = _dev(parts)
+    lib = _lib.load()
+    M, nparts, _ = parts.shape
+    coef = torch.empty(M, 2, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        check(lib.pmhip_ln_coef_parts(_p(parts), nparts, float(eps), _p(coef), M, stream_ptr(dev)), "pmhip_ln_coef_parts")
+    return coef
 
 
 def layernorm_hilo(hi, lo, gamma, beta, eps=1e-5, out_dtype=torch.bfloat16):

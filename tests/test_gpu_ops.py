@@ -122,6 +122,34 @@ def test_hilo_row_operators():
         assert rel_err(coef[:, 0], rstd) < 1e-5 and maxabs(coef[:, 1], -rstd * h64.mean(1)) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 512), (8192, 768, 768), (4096, 512, 2048), (300, 128, 64), (33 * 1024, 1024, 1024), (1024, 192, 64)])
+def test_gemm_hilo_row_statistics_and_coefficients(M, N, K):
+    """pmhip_gemm_hilo_stats: the producer's epilogue also leaves, per row and 64-column part, (sum, sum of squares about the
+    part's mean) of the NEW hi plane; pmhip_ln_coef_parts combines them into the folded LayerNorm's (rstd, -rstd * mean).  Same
+    planes as the plain producer bit for bit; statistics against float64 of the hi plane; coefficients equal to the plane pass
+    (pmhip_ln_coef) to a few ulp.  Shapes cover every GEMM route (256x128 two-workgroup, 256x256, 128x128) and ragged M."""
+    bf = torch.bfloat16
+    a, w, b0 = bf16_round(rnd(M, K, scale=0.7)), bf16_round(rnd(N, K, scale=K ** -0.5)), rnd(N)
+    res = rnd(M, N) * 1.5 + 0.4
+    rh, rl = ops.split_hilo(t(res))
+    hi0, lo0 = ops.gemm_hilo(t(a, bf), t(w, bf), rh, rl, bias=t(b0))
+    hi, lo, parts = ops.gemm_hilo(t(a, bf), t(w, bf), rh, rl, bias=t(b0), stats=True)
+    assert torch.equal(hi, hi0) and torch.equal(lo, lo0)
+    h64 = hi.double().cpu().numpy().reshape(M, N // 64, 64)
+    p = parts.cpu().numpy()
+    assert np.isfinite(p).all()
+    assert np.abs(p[..., 0] - h64.sum(-1)).max() < 2e-4
+    assert np.abs(p[..., 1] - ((h64 - h64.mean(-1, keepdims=True)) ** 2).sum(-1)).max() < 2e-3
+    coef = n(ops.ln_coef_parts(parts))
+    want = n(ops.ln_coef(hi))
+    hfull = hi.double().cpu().numpy()
+    rstd64 = 1.0 / np.sqrt(hfull.var(-1) + 1e-5)
+    assert np.abs(coef[:, 0] / rstd64 - 1).max() < 2e-6 and np.abs(coef[:, 1] + rstd64 * hfull.mean(-1)).max() < 2e-6
+    assert np.abs(coef / want - 1).max() < 4e-6, np.abs(coef / want - 1).max()
+    again = ops.gemm_hilo(t(a, bf), t(w, bf), rh, rl, bias=t(b0), stats=True)[2]
+    assert torch.equal(again, parts)                                  # deterministic (no atomics)
+
+
 @pytest.mark.parametrize("M,N,K,rows", [(65536 // 8, 512, 512, 0),      # two-workgroup kernel (short-K residual GEMM)
                                          (8192, 512, 1408, 0),          # 256x256 kernel (long K)
                                          (2048, 512, 64, 1024),         # 128x128 kernel, position-embedding addend (row modulo)
