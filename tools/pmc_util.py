@@ -12,9 +12,9 @@ import sys
 
 
 def short(name):
-    for key, tag in (("gemm256_kernel<0", "gemm256 plain (logits)"), ("gemm256_kernel<1", "gemm256 SwiGLU"),
+    for key, tag in (("gemm256_kernel<0, float", "gemm256 plain f32 out (logits)"), ("gemm256_kernel<0", "gemm256 plain bf16 out (FFN w3 residual producer)"), ("gemm256_kernel<1", "gemm256 SwiGLU"),
                      ("gemm256_kernel<2", "gemm256 head-split QKV"), ("gemm2b_kernel", "gemm2b (short-K residual)"), ("gemm_nt_kernel", "gemm128 (small)"),
-                     ("attention_bf16_kernel", "attention"), ("attention_kernel", "attention (f32 / round-2 kernel)"), ("ln_coef_kernel", "ln_coef (fold coefficients)"),
+                     ("attention_bf16_kernel", "attention"), ("attention_kernel", "attention (f32 / round-2 kernel)"), ("ln_coef_parts_kernel", "ln_coef_parts (fold coefficients from producer statistics)"), ("ln_coef_kernel", "ln_coef (fold coefficients)"),
                      ("hilo_rows_kernel", "hi/lo row operators"), ("layernorm", "layernorm"), ("sample_rows", "sample_rows"), ("vq_scan", "vq_scan")):
         if key in name:
             return tag
