@@ -75,6 +75,17 @@ __device__ __forceinline__ void burst(const f32x2 (&ab)[8], const f32x2 (&cc)[2]
                 asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(cc[ni][0]), "v"(yy), "v"(dd[ni][0]));
                 asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(out[mi][ni][1]) : "v"(xx), "v"(acc[mi][ni][1]), "v"(t0));
                 asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(out[mi][ni][0]) : "v"(xx), "v"(acc[mi][ni][0]), "v"(t1));
+            } else if constexpr (AV == 10 || AV == 11) { // HIGH half taking src1 / src2 from the LOW register (what hipcc emits to broadcast an even register)
+                f32x2 t0, t1;
+                if constexpr (AV == 10) {
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t0) : "v"(cc[ni][1]), "v"(ab[mi]), "v"(dd[ni][1]));
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t1) : "v"(cc[ni][0]), "v"(ab[mi]), "v"(dd[ni][0]));
+                } else {
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(t0) : "v"(cc[ni][1]), "v"(dd[ni][1]), "v"(ab[mi]));
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(t1) : "v"(cc[ni][0]), "v"(dd[ni][0]), "v"(ab[mi]));
+                }
+                PK_O(out[mi][ni][1], ab[mi], acc[mi][ni][1], t0);
+                PK_O(out[mi][ni][0], ab[mi], acc[mi][ni][0], t1);
             } else if constexpr (AV >= 6 && AV <= 9) {   // other low-half-from-high-register forms
                 f32x2 t0, t1;
                 if constexpr (AV == 6) {
@@ -295,6 +306,10 @@ int main(int argc, char** argv) {
     RUN(8, 1, 0, false, "v_pk_fma_f32 op_sel:[1,0,0] | setprio + 16 MFMA bf16");
     RUN(9, 1, 0, false, "v_pk_fma_f32 op_sel:[0,0,1] | setprio + 16 MFMA bf16");
     RUN(0, 6, 0, false, "pk_fma t0,t1,o0,o1 | setprio + 8 MFMA bf16 32x32x16");
+    RUN(10, 1, 0, false, "v_pk_fma_f32 op_sel_hi:[1,0,1] (high half <- src1 low register) | setprio + 16 MFMA bf16");
+    RUN(10, 1, 1, false, "v_pk_fma_f32 op_sel_hi:[1,0,1] | 16 cycles later: setprio + 16 MFMA bf16");
+    RUN(10, 1, 2, false, "v_pk_fma_f32 op_sel_hi:[1,0,1] | 32 cycles later: setprio + 16 MFMA bf16");
+    RUN(11, 1, 0, false, "v_pk_fma_f32 op_sel_hi:[1,1,0] (high half <- src2 low register) | setprio + 16 MFMA bf16");
     RUN(0, 1, 1, false, "pk_fma t0,t1,o0,o1 | 16 cycles later: setprio + 16 MFMA bf16");
     RUN(0, 1, 2, false, "pk_fma t0,t1,o0,o1 | 32 cycles later: setprio + 16 MFMA bf16");
     RUN(0, 1, 4, false, "pk_fma t0,t1,o0,o1 | 64 cycles later: setprio + 16 MFMA bf16");
