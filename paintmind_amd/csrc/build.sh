@@ -7,7 +7,7 @@ here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../libpaintmind_hip.so"
 objdir="$here/build"
 mkdir -p "$objdir"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${PM_EXTRA_FLAGS:-}"     # PM_EXTRA_FLAGS: ablation builds (tools/ab_*.sh)
 units="gemm gemm256 gemm2b attention attention_bf16 attention_dh rowops vq sample loss engine"
 hdrsum="$(cat "$here"/*.h "$here/../../include/pmhip.h" | sha256sum | cut -d' ' -f1)"
 pids=(); built=0; reused=0

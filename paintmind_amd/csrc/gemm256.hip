@@ -298,7 +298,8 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
 
         // every fragment read finished before the last barrier.  The buffer of the LAST K-tile is free for the epilogue's
         // staging (8 KiB per wave); the other one already holds the next tile's first K-tile.
-#ifdef PM_FOLD_DIRECT
+#if defined(PM_FOLD_NOAPPLY)                     // timing ablation only (results are not normalised)
+#elif defined(PM_FOLD_DIRECT)
         if constexpr (FOLD) ln_apply_direct<8>(p, c.mw, c.nw, acc, lane);
 #else
         if constexpr (FOLD) ln_apply<8>(fscr, acc, lane);          // the coefficient DMA was retired by the last K-tile's vmcnt(0)

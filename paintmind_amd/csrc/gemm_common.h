@@ -223,12 +223,15 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                                 vbuf[(ni * 16 + g * 4 + r) * 64 + mi * 16 + l15] = from_f32<OutT>(acc[blk * 4 + mi][ni][r]);
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    OutT* vrow = dst + (((size_t)b0 * p.heads + h) * 64) * p.tokens_pad + t0;
+                    // one per-lane base on each side + wave-uniform steps: eight separate row indices kept live across the
+                    // whole kernel cost the folded head-split variant two spills, reloaded here behind a vmcnt(0) that drained
+                    // the next tile's DMA (+24 us per launch)
+                    OutT* vptr = dst + (((size_t)b0 * p.heads + h) * 64 + (lane >> 3)) * p.tokens_pad + t0 + (lane & 7) * 8;
+                    const unsigned char* lptr = eraw + (lane >> 3) * 128 + (lane & 7) * 16;
+                    const size_t vstep = (size_t)8 * p.tokens_pad;
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) {                             // 8 d-rows x 128 B per store instruction
-                        const int d = it * 8 + (lane >> 3), c = (lane & 7) * 8;
-                        nt_store16(vrow + (size_t)d * p.tokens_pad + c, *reinterpret_cast<const uint4*>(vbuf + d * 64 + c));
-                    }
+                    for (int it = 0; it < 8; ++it)                               // 8 d-rows x 128 B per store instruction
+                        nt_store16(vptr + it * vstep, *reinterpret_cast<const uint4*>(lptr + it * 1024));
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 } else {

@@ -249,7 +249,7 @@ def gemm_heads_ln(xb, wg, heads, tokens, kinds, q_scale, coef, c, d):
     outs = []
     for kind in kinds:
         shape = (B, heads, tokens, 64) if kind == PART_Q else ((B, heads, tp, 64) if kind == PART_K else (B, heads, 64, tp))
-        outs.append(torch.zeros(shape, device=dev, dtype=xb.dtype))
+        outs.append(torch.empty(shape, device=dev, dtype=xb.dtype))
     kinds_c = (C.c_int * len(kinds))(*kinds)
     outs_c = (C.c_void_p * len(kinds))(*[o.data_ptr() for o in outs])
     ln = _lnfold(coef, c, d)
