@@ -237,7 +237,7 @@ int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W
         // with the LayerNorm folded into the consumers the producer's epilogue also leaves the row statistics of the new hi plane
         // (16 bytes per 64 columns): the coefficient pass over the plane (pmhip_ln_coef, 14 us per launch at the bench shape)
         // becomes a combination of 8-16 partials per row.  PMHIP_LN_STATS=0: the pass (A/B).
-        b.parts_valid = b.fold && N % 64 == 0 && ln_stats_enabled();
+        b.parts_valid = b.fold && N % 64 == 0 && N <= 1024 && ln_stats_enabled();   // pmhip_ln_coef_parts combines <= 16 parts
         if (b.parts_valid) return pmhip_gemm_hilo_stats(A, lda, W, ldw, bias, r.hi, r.lo, r.ld, r.rows, b.xh, b.xl, N, M, N, K, b.parts, s);
         return pmhip_gemm_hilo(A, lda, W, ldw, bias, r.hi, r.lo, r.ld, r.rows, b.xh, b.xl, N, M, N, K, s);
     }
