@@ -1,3 +1,4 @@
+// build check: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I paintmind_amd/csrc -I include -c tools/experiments/attention_bf16_persistent.hip
 // EXPERIMENT, not built into the library: the round-3 bf16 attention kernel made PERSISTENT -- 512
 // workgroups, each walking several (batch, head)s at one query-block index, K / V^T ring running across the item boundary, next
 // item's Q requested into the dead Q registers before the output is normalised, output through a private staging area.
