@@ -356,7 +356,10 @@ int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const f
  * is bracketed by hipEvents on its own stream and accumulated (count, total ms). */
 int pmhip_timing_enable(int on);
 int pmhip_timing_reset(void);
-/* family: "gemm", "attention", "layernorm", "sample", "vq", "rowops"; returns PMHIP_EINVAL if unknown */
+/* family: "gemm" (all GEMM launches = the sum of "gemm_plain", "gemm_heads", "gemm_swiglu", "gemm_resid", "gemm_resid2b": bias-only /
+ * head-split q|k|v / SwiGLU w12 / residual producers on the one-workgroup kernels / on the two-workgroups-per-CU kernel),
+ * "attention", "layernorm", "sample", "vq", "rowops"; returns PMHIP_EINVAL if unknown.  The accumulators are process-wide and
+ * guarded by a mutex; while timing is on pmhip_pipeline_generate runs eagerly (no graph replay). */
 int pmhip_timing_get(const char* family, int* launches, double* total_ms);
 
 #ifdef __cplusplus

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -43,7 +44,14 @@ void pm_set_error(const char* fmt, ...);
 // ---------------------------------------------------------------------------------------------
 // per-family kernel timing (bench.py's roofline leg).  Off by default: zero overhead.
 // ---------------------------------------------------------------------------------------------
-enum PmFamily { FAM_GEMM = 0, FAM_ATTENTION, FAM_LAYERNORM, FAM_SAMPLE, FAM_VQ, FAM_ROWOPS, FAM_COUNT };
+// The GEMM launches are kept per kind so that bench.py can price every kernel of the family against its own roofline:
+//   FAM_GEMM        plain (bias only): logits, patch embedding, prev_quant, the decoder's pixel projection, context projection
+//   FAM_GEMM_HEADS  head-split q|k|v projections          FAM_GEMM_SWIGLU  w12 with the gate in the epilogue
+//   FAM_GEMM_RESID  residual producers on the 256x256 / 128x128 kernels (FFN w3, token / post-quant projections)
+//   FAM_GEMM_RESID2B  residual producers on the two-workgroups-per-CU kernel (attention out-projections)
+// pmhip_timing_get("gemm") is the sum of the five.
+enum PmFamily { FAM_GEMM = 0, FAM_ATTENTION, FAM_LAYERNORM, FAM_SAMPLE, FAM_VQ, FAM_ROWOPS, FAM_GEMM_HEADS, FAM_GEMM_SWIGLU, FAM_GEMM_RESID,
+                FAM_GEMM_RESID2B, FAM_COUNT };
 struct PmTimer {
     PmTimer(int family, hipStream_t s);
     ~PmTimer();
@@ -52,7 +60,7 @@ struct PmTimer {
     hipEvent_t e0;
     bool on;
 };
-extern bool g_pm_timing_on;
+extern std::atomic<bool> g_pm_timing_on;
 
 // ---------------------------------------------------------------------------------------------
 // per-call scalars of a hipGraph-replayed decode loop (device memory, refreshed before every replay)

@@ -4,8 +4,11 @@
 // library on one HIP stream.  No host synchronisation happens inside a forward pass.
 #include <stdarg.h>
 
+#include <algorithm>
+#include <atomic>
 #include <map>
 #include <memory>
+#include <mutex>
 
 #include "common.h"
 
@@ -35,15 +38,20 @@ extern "C" int pmhip_device_info(int device, int* cu_count, int* lds_bytes, char
     return PMHIP_OK;
 }
 
-bool g_pm_timing_on = false;
+// Timing is a process-wide diagnostic that concurrent lanes (one host thread each, generate.py) may run into: the switch is
+// atomic and the per-family accumulators are guarded by one mutex (taken only while timing is on).
+std::atomic<bool> g_pm_timing_on{false};
 namespace {
+std::mutex g_fam_mu;
 struct FamStat {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int launches = 0;
     double ms = 0.0;
 };
 FamStat g_fam[FAM_COUNT];
-const char* kFamNames[FAM_COUNT] = {"gemm", "attention", "layernorm", "sample", "vq", "rowops"};
+const char* kFamNames[FAM_COUNT] = {"gemm_plain", "attention", "layernorm", "sample", "vq", "rowops", "gemm_heads", "gemm_swiglu", "gemm_resid",
+                                    "gemm_resid2b"};
+const int kGemmFams[5] = {FAM_GEMM, FAM_GEMM_HEADS, FAM_GEMM_SWIGLU, FAM_GEMM_RESID, FAM_GEMM_RESID2B};
 
 void drain(FamStat& f) {
     for (auto& pr : f.pending) {
@@ -59,7 +67,7 @@ void drain(FamStat& f) {
 }
 }  // namespace
 
-PmTimer::PmTimer(int fam, hipStream_t s) : family(fam), stream(s), e0(nullptr), on(g_pm_timing_on) {
+PmTimer::PmTimer(int fam, hipStream_t s) : family(fam), stream(s), e0(nullptr), on(g_pm_timing_on.load(std::memory_order_relaxed)) {
     if (on) {
         if (hipEventCreate(&e0) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(e0, stream);
@@ -70,17 +78,28 @@ PmTimer::~PmTimer() {
     hipEvent_t e1;
     if (hipEventCreate(&e1) != hipSuccess) return;
     (void)hipEventRecord(e1, stream);
+    std::lock_guard<std::mutex> lk(g_fam_mu);
     g_fam[family].pending.emplace_back(e0, e1);
 }
 
-extern "C" int pmhip_timing_enable(int on) { g_pm_timing_on = on != 0; return PMHIP_OK; }
+extern "C" int pmhip_timing_enable(int on) { g_pm_timing_on.store(on != 0); return PMHIP_OK; }
 extern "C" int pmhip_timing_reset(void) {
+    std::lock_guard<std::mutex> lk(g_fam_mu);
     for (auto& f : g_fam) { drain(f); f.launches = 0; f.ms = 0.0; }
     return PMHIP_OK;
 }
 extern "C" int pmhip_timing_get(const char* family, int* launches, double* total_ms) {
+    if (family && std::string(family) == "gemm") {           // the whole GEMM family
+        std::lock_guard<std::mutex> lk(g_fam_mu);
+        int n = 0; double ms = 0.0;
+        for (int i : kGemmFams) { drain(g_fam[i]); n += g_fam[i].launches; ms += g_fam[i].ms; }
+        if (launches) *launches = n;
+        if (total_ms) *total_ms = ms;
+        return PMHIP_OK;
+    }
     for (int i = 0; i < FAM_COUNT; ++i)
         if (family && std::string(family) == kFamNames[i]) {
+            std::lock_guard<std::mutex> lk(g_fam_mu);
             drain(g_fam[i]);
             if (launches) *launches = g_fam[i].launches;
             if (total_ms) *total_ms = g_fam[i].ms;
@@ -152,6 +171,8 @@ struct TowerBufs {
     float* parts = nullptr; // ... and the partial row statistics the last residual GEMM left behind, [M, dim/64, 2]
     bool parts_valid = false;   // parts describe the CURRENT hi plane (set by residual_gemm, see tower_coef)
     bool hilo = false;      // bf16 mode
+    int fold_rows_cap = 0;  // Switches::fold_rows_cap
+    bool stats = true;      // producers leave row statistics (PMHIP_LN_STATS=0: the coefficient pass over the plane, A/B tests)
     bool fold = false;      // hilo and folding not disabled (PMHIP_LN_UNFOLD=1 forces the separate LayerNorm kernel: A/B tests)
 };
 
@@ -175,33 +196,44 @@ int check_dim_head(const char* who, const pmhip_tower_cfg& tc) {
     return PMHIP_OK;
 }
 
-// The bf16 hi/lo residual stream + folded LayerNorm is the DEFAULT of bf16 mode (PMHIP_HILO=0, read on every forward, restores
+// The bf16 hi/lo residual stream + folded LayerNorm is the DEFAULT of bf16 mode (PMHIP_HILO=0, read when a handle is created, restores
 // the fp32 stream + LayerNorm kernel of rounds 1-2): 1.3 % faster on the default workload (same box: 476.5 vs 470.6 images/s),
 // as accurate.  It was opt-in while 3-11 of 1800 generate() calls under concurrent lanes were not
 // bit-identical; that was a gfx950 packed-FP32 operand-select hazard in the folded epilogue, fixed in
 // gemm_common.h and gated by tests/test_isa_hazards.py.
-bool hilo_enabled() {
-    const char* e = getenv("PMHIP_HILO");
-    return !(e && atoi(e) == 0);
-}
+// The PMHIP_* switches are read ONCE, when a handle is created (a handle's graphs, workspace and fold decisions all depend on
+// them; a getenv on the hot path is also a data race with a caller that edits the environment from another thread).
+struct Switches {
+    bool hilo = true;       // PMHIP_HILO=0: the fp32 stream + LayerNorm kernel of rounds 1-2
+    bool fold = true;       // PMHIP_LN_UNFOLD=1: the hi/lo pair, but the separate LayerNorm kernel
+    bool stats = true;      // PMHIP_LN_STATS=0: fold coefficients by a pass over the hi plane
+    static Switches from_env() {
+        Switches w;
+        const char* e = getenv("PMHIP_HILO");
+        w.hilo = !(e && atoi(e) == 0);
+        e = getenv("PMHIP_LN_UNFOLD");
+        w.fold = !(e && atoi(e) != 0);
+        e = getenv("PMHIP_LN_STATS");
+        w.stats = !(e && atoi(e) == 0);
+        e = getenv("PMHIP_FOLD_MAX_ROWS");
+        w.fold_rows_cap = e ? atoi(e) : 0;
+        return w;
+    }
+    int fold_rows_cap = 0;  // PMHIP_FOLD_MAX_ROWS (development / tests): cap on the rows one folded launch takes, see fold_rows()
+    int key() const { return (hilo ? 2 : 0) + (fold ? 1 : 0) + (stats ? 4 : 0); }
+};
 
-bool ln_stats_enabled() {
-    const char* e = getenv("PMHIP_LN_STATS");
-    return !(e && atoi(e) == 0);
-}
+// widest residual stream the hi/lo row operators (pmhip_split_hilo, pmhip_layernorm_hilo, pmhip_layernorm_to_hilo, pmhip_ln_coef,
+// pmhip_join_hilo: one wave per row, the row in registers) serve; wider bf16 towers keep the fp32 stream + pmhip_layernorm
+constexpr int kHiloMaxDim = 1024;
 
-bool ln_fold_enabled() {
-    const char* e = getenv("PMHIP_LN_UNFOLD");
-    return !(e && atoi(e) != 0);
-}
-
-int alloc_tower(Workspace& ws, const char* tag, int dtype, const pmhip_tower_cfg& tc, int B, int tokens, TowerBufs& b,
+int alloc_tower(Workspace& ws, const Switches& sw, const char* tag, int dtype, const pmhip_tower_cfg& tc, int B, int tokens, TowerBufs& b,
                 hipStream_t s) {
     const size_t es = dtype_size(dtype);
     const size_t M = (size_t)B * tokens;
     const int dh = dh_of(tc), inner = tc.heads * dh, Np = round_up(tokens, 64);
     std::string t(tag);
-    b.hilo = dtype == PMHIP_BF16 && hilo_enabled();
+    b.hilo = dtype == PMHIP_BF16 && sw.hilo && tc.dim <= kHiloMaxDim;
     if (b.hilo) {
         WS(ws, (t + ".xh").c_str(), M * tc.dim * 2, b.xh);
         WS(ws, (t + ".xl").c_str(), M * tc.dim * 2, b.xl);
@@ -219,7 +251,9 @@ int alloc_tower(Workspace& ws, const char* tag, int dtype, const pmhip_tower_cfg
     b.parts_valid = false;
     b.split = nullptr;
     if (dh != 64) WS(ws, (t + ".split").c_str(), M * 3 * inner * 4, b.split);
-    b.fold = b.hilo && dh == 64 && ln_fold_enabled();
+    b.fold = b.hilo && dh == 64 && sw.fold;
+    b.stats = sw.stats;
+    b.fold_rows_cap = sw.fold_rows_cap;
     return PMHIP_OK;
 }
 
@@ -237,7 +271,7 @@ int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W
         // with the LayerNorm folded into the consumers the producer's epilogue also leaves the row statistics of the new hi plane
         // (16 bytes per 64 columns): the coefficient pass over the plane (pmhip_ln_coef, 14 us per launch at the bench shape)
         // becomes a combination of 8-16 partials per row.  PMHIP_LN_STATS=0: the pass (A/B).
-        b.parts_valid = b.fold && N % 64 == 0 && N <= 1024 && ln_stats_enabled();   // pmhip_ln_coef_parts combines <= 16 parts
+        b.parts_valid = b.fold && N % 64 == 0 && N <= 1024 && b.stats;   // pmhip_ln_coef_parts combines <= 16 parts
         if (b.parts_valid) return pmhip_gemm_hilo_stats(A, lda, W, ldw, bias, r.hi, r.lo, r.ld, r.rows, b.xh, b.xl, N, M, N, K, b.parts, s);
         return pmhip_gemm_hilo(A, lda, W, ldw, bias, r.hi, r.lo, r.ld, r.rows, b.xh, b.xl, N, M, N, K, s);
     }
@@ -259,7 +293,22 @@ int tower_layernorm(int dtype, TowerBufs& b, const float* g, const float* be, in
 // Folded or not must not depend on the BATCH (the two routes differ in rounding, and an image's result may not depend on
 // how many images run with it -- lanes, ranks and batch sizes all give bit-identical images): the decision looks at the
 // per-image row count and the weight shape only, and the 256x256 kernel then takes the shape whatever its tile count.
-bool fold_shape_ok(int tokens, int n_out, int dim) { return tokens % 256 == 0 && n_out % 256 == 0 && dim % 128 == 0; }
+// The 256x256 kernel addresses its operands with 32-bit byte offsets (set_lnfold in gemm.hip refuses M * lda * 2 >= 2^31): the
+// weight and ONE image's rows must fit -- a larger batch is cut into launches of whole images by fold_rows(), so the decision
+// stays a function of the shape and the result stays bit-identical for every batch size.
+bool fold_shape_ok(int tokens, int n_out, int dim) {
+    return tokens % 256 == 0 && n_out % 256 == 0 && dim % 128 == 0 && dim >= 128 && (unsigned long long)n_out * dim * 2 < (1ull << 31) &&
+           (unsigned long long)tokens * dim * 2 < (1ull << 31);
+}
+
+// rows one folded launch may take: whole images, below the 32-bit byte-offset limit
+int fold_rows(const TowerBufs& b, int M, int tokens, int dim) {
+    long long rows = ((1ll << 31) - 1) / ((long long)dim * 2);
+    if (b.fold_rows_cap > 0 && b.fold_rows_cap < rows) rows = b.fold_rows_cap;
+    long long imgs = rows / tokens;
+    if (imgs < 1) imgs = 1;
+    return (int)std::min<long long>(M, imgs * tokens);
+}
 
 // LN(x) -> head-split projection: folded when the shape is served, else LayerNorm + GEMM
 int ln_heads(int dtype, TowerBufs& b, const float* g, const float* be, const void* W, const void* Wf, const float* fc, const float* fd,
@@ -267,8 +316,18 @@ int ln_heads(int dtype, TowerBufs& b, const float* g, const float* be, const voi
              hipStream_t s) {
     if (b.fold && Wf && fold_shape_ok(tokens, nparts * heads * 64, dim)) {
         PM_TRY(tower_coef(b, M, dim, s));
-        const pmhip_lnfold ln{b.coef, fc, fd};
-        return pmhip_gemm_heads_ln(dtype, b.xh, dim, Wf, dim, M, dim, heads, tokens, Np, nparts, kinds, outs, q_scale, &ln, s);
+        const int step = fold_rows(b, M, tokens, dim);
+        for (int m0 = 0; m0 < M; m0 += step) {
+            const int rows = std::min(step, M - m0);
+            const size_t b0 = (size_t)(m0 / tokens);
+            void* o[3] = {nullptr, nullptr, nullptr};
+            for (int i = 0; i < nparts; ++i)
+                o[i] = reinterpret_cast<unsigned char*>(outs[i]) + b0 * heads * (kinds[i] == PMHIP_PART_Q ? tokens : Np) * 64 * dtype_size(dtype);
+            const pmhip_lnfold ln{b.coef + (size_t)m0 * 2, fc, fd};
+            PM_TRY(pmhip_gemm_heads_ln(dtype, reinterpret_cast<const unsigned char*>(b.xh) + (size_t)m0 * dim * 2, dim, Wf, dim, rows, dim, heads,
+                                       tokens, Np, nparts, kinds, o, q_scale, &ln, s));
+        }
+        return PMHIP_OK;
     }
     PM_TRY(tower_layernorm(dtype, b, g, be, M, dim, s));
     return pmhip_gemm_heads_dh(dtype, b.y, dim, W, dim, M, dim, heads, dh, tokens, Np, nparts, kinds, outs, q_scale, b.split, s);
@@ -313,8 +372,13 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
     // x = ffnet(norm(x)) + x
     if (b.fold && L.w12p_f && fold_shape_ok(tokens, 2 * tc.hidden_pad, dim)) {
         PM_TRY(tower_coef(b, M, dim, s));
-        const pmhip_lnfold ln{b.coef, L.w12_c, L.w12_d};
-        PM_TRY(pmhip_gemm_swiglu_ln(dtype, b.xh, dim, L.w12p_f, L.b12p, b.hid, tc.hidden_pad, M, tc.hidden_pad, dim, &ln, s));
+        const int step = fold_rows(b, M, tokens, dim);
+        for (int m0 = 0; m0 < M; m0 += step) {
+            const pmhip_lnfold ln{b.coef + (size_t)m0 * 2, L.w12_c, L.w12_d};
+            PM_TRY(pmhip_gemm_swiglu_ln(dtype, reinterpret_cast<const unsigned char*>(b.xh) + (size_t)m0 * dim * 2, dim, L.w12p_f, L.b12p,
+                                        reinterpret_cast<unsigned char*>(b.hid) + (size_t)m0 * tc.hidden_pad * dtype_size(dtype), tc.hidden_pad,
+                                        std::min(step, M - m0), tc.hidden_pad, dim, &ln, s));
+        }
     } else {
         PM_TRY(tower_layernorm(dtype, b, L.ln2_g, L.ln2_b, M, dim, s));
         PM_TRY(pmhip_gemm_swiglu(dtype, b.y, dim, L.w12p, L.b12p, b.hid, tc.hidden_pad, M, tc.hidden_pad, dim, s));
@@ -354,6 +418,7 @@ struct pmhip_vqgan {
     std::vector<pmhip_layer_weights> enc_layers, dec_layers;
     int grid = 0, tokens = 0, patch_k = 0;
     Workspace ws;
+    Switches sw = Switches::from_env();
     bool dec_pos_split = false;     // bf16 mode: the decoder position embedding has been split into hi / lo planes (ws "decpos.*")
 };
 
@@ -394,7 +459,7 @@ namespace {
 int vq_encoder(pmhip_vqgan* h, const float* img, int B, TowerBufs& tb, hipStream_t s) {
     const auto& c = h->cfg;
     const int M = B * h->tokens, dim = c.enc.dim;
-    PM_TRY(alloc_tower(h->ws, "enc", h->dtype, c.enc, B, h->tokens, tb, s));
+    PM_TRY(alloc_tower(h->ws, h->sw, "enc", h->dtype, c.enc, B, h->tokens, tb, s));
     void* pa; float* x0;
     WS(h->ws, "enc.patches", (size_t)M * h->patch_k * dtype_size(h->dtype), pa);
     WS(h->ws, "enc.x0", (size_t)M * dim * 4, x0);
@@ -430,7 +495,7 @@ int vq_decode_latent(pmhip_vqgan* h, const void* zp, int B, float* img_out, hipS
     const auto& c = h->cfg;
     const int M = B * h->tokens, dim = c.dec.dim;
     TowerBufs tb;
-    PM_TRY(alloc_tower(h->ws, "dec", h->dtype, c.dec, B, h->tokens, tb, s));
+    PM_TRY(alloc_tower(h->ws, h->sw, "dec", h->dtype, c.dec, B, h->tokens, tb, s));
     // post_quant + position embedding fused (vqmodel.py:28, layers.py:146)
     ResSrc pos;
     PM_TRY(pos_source(h->ws, "decpos", tb.hilo, h->w.dec_pos, h->tokens, dim, h->dec_pos_split, pos, s));
@@ -503,7 +568,7 @@ extern "C" int pmhip_vqgan_decoder_forward(pmhip_vqgan* h, const float* x, int B
     hipStream_t s = (hipStream_t)stream;
     const int M = B * h->tokens;
     TowerBufs tb;
-    PM_TRY(alloc_tower(h->ws, "dec", h->dtype, h->cfg.dec, B, h->tokens, tb, s));
+    PM_TRY(alloc_tower(h->ws, h->sw, "dec", h->dtype, h->cfg.dec, B, h->tokens, tb, s));
     if (tb.hilo) {
         float* x0;
         WS(h->ws, "dec.x0", (size_t)M * h->cfg.dec.dim * 4, x0);
@@ -536,6 +601,7 @@ struct pmhip_s2 {
     std::vector<pmhip_layer_weights> layers;
     std::vector<CrossKV> cross;     // per layer, valid after prepare_context
     Workspace ws;
+    Switches sw = Switches::from_env();
     bool pos_split = false;         // bf16 mode: position embedding split into hi / lo planes (ws "pos.*")
     std::map<std::string, GraphEntry> graphs;   // captured decode loops, keyed by shape / schedule structure
     hipStream_t capture_stream = nullptr;       // capture never happens on the caller's stream (it may be the NULL stream)
@@ -630,7 +696,7 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s) {
     const auto& c = h->cfg;
     const int M = B * c.tokens, dim = c.tower.dim;
     TowerBufs tb;
-    PM_TRY(alloc_tower(h->ws, "s2", h->dtype, c.tower, B, c.tokens, tb, s));
+    PM_TRY(alloc_tower(h->ws, h->sw, "s2", h->dtype, c.tower, B, c.tokens, tb, s));
     ResSrc pos;
     PM_TRY(pos_source(h->ws, "pos", tb.hilo, h->w.pos, c.tokens, dim, h->pos_split, pos, s));
     PM_TRY(residual_gemm(h->dtype, tb, tp, 64, h->w.tokproj_w, 64, h->w.tokproj_b, pos, M, dim, 64, s));
@@ -638,9 +704,13 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s) {
         PM_TRY(layer_forward(h->dtype, h->layers[l], c.tower, tb, B, c.tokens, true, &h->cross[l], s));
     if (tb.fold && h->w.logits_wf && fold_shape_ok(c.tokens, c.n_embed, dim)) {
         PM_TRY(tower_coef(tb, M, dim, s));
-        const pmhip_lnfold ln{tb.coef, h->w.logits_c, h->w.logits_d};                    // the final norm folded into to_logits
-        return pmhip_gemm_ln(h->dtype, tb.xh, dim, h->w.logits_wf, dim, h->w.logits_b, logits, c.n_embed, PMHIP_F32, M, c.n_embed, dim,
-                             &ln, s);
+        const int step = fold_rows(tb, M, c.tokens, dim);
+        for (int m0 = 0; m0 < M; m0 += step) {
+            const pmhip_lnfold ln{tb.coef + (size_t)m0 * 2, h->w.logits_c, h->w.logits_d};   // the final norm folded into to_logits
+            PM_TRY(pmhip_gemm_ln(h->dtype, reinterpret_cast<const unsigned char*>(tb.xh) + (size_t)m0 * dim * 2, dim, h->w.logits_wf, dim,
+                                 h->w.logits_b, logits + (size_t)m0 * c.n_embed, c.n_embed, PMHIP_F32, std::min(step, M - m0), c.n_embed, dim, &ln, s));
+        }
+        return PMHIP_OK;
     }
     PM_TRY(tower_layernorm(h->dtype, tb, h->w.norm_g, h->w.norm_b, M, dim, s));
     return pmhip_gemm(h->dtype, tb.y, dim, h->w.logits_w, dim, h->w.logits_b, nullptr, 0, 0, logits, c.n_embed, PMHIP_F32, M,
@@ -712,7 +782,7 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
     for (int t = 0; t < T; ++t) n_dec += (decode_host && decode_host[t]) ? 1 : 0;
     PM_REQUIRE(n_dec == 0 || (vq && (imgs_out || imgs_host)), "pipeline_generate: decode requested without vqgan / an image destination");
     PM_REQUIRE(!imgs_host || host_stride >= img_elems, "pipeline_generate: host_stride smaller than one image batch");
-    const bool graph = use_graph && !g_pm_timing_on && T <= PM_MAX_STEPS;
+    const bool graph = use_graph && !g_pm_timing_on.load() && T <= PM_MAX_STEPS;
 
     if (imgs_host) {
         const unsigned evflags = hipEventDisableTiming;
@@ -799,7 +869,7 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
 
     std::string key = "B" + std::to_string(B) + "T" + std::to_string(T) + "k" + std::to_string(topk) + "L" +
                       std::to_string(context ? L : 0) + "v" + std::to_string(vq ? vq->uid : 0) + "f" +
-                      std::to_string((hilo_enabled() ? 2 : 0) + (ln_fold_enabled() ? 1 : 0) + (ln_stats_enabled() ? 4 : 0)) + "d";
+                      std::to_string(s2->sw.key() * 8 + (vq ? vq->sw.key() : 0)) + "d";
     for (int t = 0; t < T; ++t) key += (decode_host && decode_host[t]) ? '1' : '0';
     GraphEntry& ge = s2->graphs[key];
 

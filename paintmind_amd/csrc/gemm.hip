@@ -135,7 +135,7 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
 template <typename T, int EPI, typename OutT>
 int launch(const GemmParams& p, hipStream_t s) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    PmTimer tm(FAM_GEMM, s);
+    PmTimer tm(gemm_family(p, EPI), s);
     hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, OutT>), dim3(tiles), dim3(THREADS), 0, s, p);
     PM_HIP(hipGetLastError());
     return PMHIP_OK;

@@ -338,7 +338,7 @@ int launch256(const GemmParams& p0, hipStream_t s) {
     static int persist = -1;                     // PMHIP_PERSIST256: workgroups of the persistent grid (0 = one per tile)
     if (persist < 0) { const char* e = getenv("PMHIP_PERSIST256"); persist = e ? atoi(e) : 256; }
     const int grid = (persist > 0 && tiles > persist) ? persist : tiles;
-    PmTimer tm(FAM_GEMM, s);
+    PmTimer tm(gemm_family(p, EPI), s);
     if (p.ln_coef) hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, true>), dim3(grid), dim3(THREADS), 0, s, p);
     else hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, false>), dim3(grid), dim3(THREADS), 0, s, p);
     PM_HIP(hipGetLastError());

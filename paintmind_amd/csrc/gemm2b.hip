@@ -151,7 +151,7 @@ int launch2b(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.chunk = g_chunk2b;
     const int tiles = (p.M / BM) * (p.N / BN);
-    PmTimer tm(FAM_GEMM, s);
+    PmTimer tm(gemm_family(p, EPI, true), s);
     hipLaunchKernelGGL((gemm2b_kernel<EPI, OutT>), dim3(tiles), dim3(THREADS), 0, s, p);
     PM_HIP(hipGetLastError());
     return PMHIP_OK;

@@ -40,6 +40,14 @@ struct GemmParams {
     const float* ln_c; const float* ln_d;          // [N]: c = sum_k bf16(gamma_k W_nk), d = sum_k beta_k W_nk
 };
 
+// timing family of a launch (common.h)
+inline int gemm_family(const GemmParams& p, int epi, bool two_wg = false) {
+    if (epi == EPI_HEADS) return FAM_GEMM_HEADS;
+    if (epi == EPI_SWIGLU) return FAM_GEMM_SWIGLU;
+    if (p.residual || p.out_lo) return two_wg ? FAM_GEMM_RESID2B : FAM_GEMM_RESID;
+    return FAM_GEMM;
+}
+
 // XCD-aware, bijective block remap: consecutive virtual ids stay on one XCD's L2 (block b runs on XCD b % 8).
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     const int q = nblocks >> 3, r = nblocks & 7;

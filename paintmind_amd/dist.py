@@ -42,9 +42,13 @@ def generate_sharded(pipe, text, seed, group=None, dst=0, timesteps=18, save_int
     Returns on rank `dst` the same list-of-tensors structure the single-process call returns for the full
     prompt list (bit-identical for the same seed); other ranks get None.
 
-    Every rank issues the SAME number of gathers: it depends only on (timesteps, save_interval), the steps whose
-    image Pipeline.generate returns (generate.py:195-196).  A rank whose shard is empty (fewer prompts than ranks)
-    contributes zero-row tensors of the agreed image shape instead of skipping the collective."""
+    ONE collective per call: the images of all saved steps of a rank are stacked into one
+    [n_local, n_saved, C, H, W] tensor and gathered once; rank `dst` moves the result to the host with one copy.  The
+    number of saved steps depends only on (timesteps, save_interval) (generate.py:195-196) and the image shape on the
+    pipeline (`pipe.image_shape`), so a rank whose shard is empty (fewer prompts than ranks) joins the same gather with
+    a zero-row tensor without asking anybody.  Only a pipeline object that does not expose `image_shape` needs one small
+    all_gather of the shape in that case -- which every rank then joins: rank-local facts never decide how many
+    collectives a rank issues."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     counts = [shard_range(len(text), r, world)[1] - shard_range(len(text), r, world)[0] for r in range(world)]
@@ -55,25 +59,26 @@ def generate_sharded(pipe, text, seed, group=None, dst=0, timesteps=18, save_int
     tm = getattr(pipe, "text_model", None)
     if tm is not None and hasattr(tm, "base_index"):
         tm.base_index = lo                                   # synthetic text features are keyed by global index
-    imgs = []
+    on = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    stacked = None
     if hi > lo:
         imgs = pipe.generate(text[lo:hi], timesteps=timesteps, save_interval=save_interval, seed=seed, image_base=lo,
                              keep_on_device=True, **kwargs)
         if len(imgs) != n_out:
             raise RuntimeError(f"generate returned {len(imgs)} images, the schedule implies {n_out}")
-    if min(counts) == 0:
-        # the empty ranks need the image shape to pad with: agreed through one small all_gather that EVERY rank joins
-        # (rank-local facts must never decide how many collectives a rank issues)
-        on = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        tail = list(imgs[0].shape[1:]) if imgs else []
-        info = torch.tensor([len(tail)] + tail + [0] * (7 - len(tail)), dtype=torch.int64, device=on)
+        stacked = torch.stack(list(imgs), dim=1)             # [n_local, n_saved, C, H, W]
+    tail = getattr(pipe, "image_shape", None)
+    if min(counts) == 0 and tail is None:
+        mine = list(stacked.shape[2:]) if stacked is not None else []
+        info = torch.tensor([len(mine)] + mine + [0] * (7 - len(mine)), dtype=torch.int64, device=on)
         allinfo = [torch.empty_like(info) for _ in range(world)]
         dist.all_gather(allinfo, info, group=group)
         src = next(a for a, c in zip(allinfo, counts) if c > 0).cpu().tolist()
-        if not imgs:
-            imgs = [torch.zeros([0] + src[1:1 + src[0]], dtype=torch.float32, device=on) for _ in range(n_out)]
-    out = []
-    for t in range(n_out):
-        g = gather_images(imgs[t], counts, dst=dst, group=group)
-        out.append(g.cpu() if g is not None else None)
-    return out if rank == dst else None
+        tail = src[1:1 + src[0]]
+    if stacked is None:
+        stacked = torch.zeros([0, n_out] + [int(d) for d in tail], dtype=torch.float32, device=on)
+    g = gather_images(stacked, counts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    g = g.transpose(0, 1).contiguous().cpu()                 # [n_saved, n, C, H, W]: one device-to-host copy of the whole result
+    return list(g)                                           # contiguous (n, C, H, W) tensors, like the single-process call

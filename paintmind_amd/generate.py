@@ -9,6 +9,7 @@ ALL positions, confidence from the unfiltered softmax, >= 1 token re-masked on t
 The masked-token objective (forward / loss / random_masking, generate.py:78-146) is built forward-only: no backward.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -54,7 +55,18 @@ class _PinnedPool:
 
     @staticmethod
     def _free(t):
-        return torch._C._storage_Use_Count(t.untyped_storage()._cdata) <= 2
+        # private torch API; without it a buffer is never handed out twice (every call page-locks a fresh one: slower, safe)
+        use_count = getattr(torch._C, "_storage_Use_Count", None)
+        if use_count is None:
+            return False
+        try:
+            return use_count(t.untyped_storage()._cdata) <= 2
+        except Exception:
+            return False
+
+    def discard(self, t):
+        """forget a buffer whose contents may still be written by copies in flight (a lane failed): it is never reused"""
+        self.bufs = [b for b in self.bufs if b.untyped_storage().data_ptr() != t.untyped_storage().data_ptr()]
 
     def get(self, shape):
         n = 1
@@ -117,6 +129,11 @@ class Pipeline(nn.Module):
         nn.init.normal_(self.mask_token, std=.02)
         self._pm_dtype = torch.float32
         self._engine = None
+
+    @property
+    def image_shape(self):
+        """(C, H, W) of the images this pipeline returns (used by dist.generate_sharded for ranks with an empty shard)"""
+        return (self.vqgan.encoder.to_patch_embedding[0].in_channels, self.image_size, self.image_size)
 
     # -- precision / engines ------------------------------------------------------------------------
     def set_compute_dtype(self, dtype):
@@ -345,7 +362,13 @@ class Pipeline(nn.Module):
             # pmhip_pipeline_generate), so every lane is driven by its own thread; ctypes drops the GIL during the call
             pool = _lane_thread_pool(streams)
             futs = [pool.submit(run_lane, i, e, v, st) for i, (e, v, st) in enumerate(lanes)]
-            parts = [f.result() for f in futs]               # re-raises a lane's exception here
+            # wait for EVERY lane before a failure is reported: the other lanes keep copying into the caller's host buffer
+            # until their native call returns
+            done = [(f.exception(), f) for f in futs]
+            for err, _ in done:
+                if err is not None:
+                    raise err
+            parts = [f.result() for _, f in done]
         if not join:
             return parts
         return self.join_lanes(parts)
@@ -370,7 +393,19 @@ class Pipeline(nn.Module):
         in bf16 mode the batch runs as two concurrent micro-batch lanes, and every saved image starts its copy into a
         pinned host buffer on a copy stream as soon as its step is done (the reference's blocking `img.cpu()` per saved
         step, generate.py:195-196), so only the last image's copy is exposed.  use_graph / streams override the defaults;
-        results are bit-identical for every setting (tests/test_gpu_model.py)."""
+        results are bit-identical for every setting (tests/test_gpu_model.py).
+
+        Resource profile of the defaults (differs from a plain eager loop): the second lane owns a clone of both native
+        handles -- its own workspace (sized for its share of the batch, so the total stays about the single-stream
+        workspace: 6 GiB at B = 64 with vit-s + 12L/d512), its own captured graphs and its own handle-owned image buffer;
+        the lanes are driven by a process-wide thread pool (one thread per lane, blocked in the native call between
+        segments).  Opt out per call with streams=1 / use_graph=False, or process-wide with the environment variables
+        PMHIP_GENERATE_STREAMS=1 and PMHIP_GENERATE_GRAPH=0 (read at every call).
+
+        The returned tensors are views of ONE pinned host buffer [n_saved, B, C, H, W] that the package reuses once no
+        tensor (or numpy alias) of an earlier call is alive: keeping one image keeps the whole buffer page-locked, and an
+        asynchronous `.to('cuda', non_blocking=True)` of a returned image must be synchronised before the LAST reference to
+        the list is dropped.  `.clone()` a result to own ordinary pageable memory, as the reference's `img.cpu()` returns."""
         B = len(text)
         context = self.text_model(text)
         if self._on_cpu():
@@ -379,9 +414,12 @@ class Pipeline(nn.Module):
         if seed is None:
             seed = _draw_seed()
         if use_graph is None:
-            use_graph = True
+            use_graph = os.environ.get("PMHIP_GENERATE_GRAPH", "1") != "0"
         if streams is None:
             streams = 2 if (self.compute_dtype == torch.bfloat16 and B >= 8) else 1
+            env_streams = os.environ.get("PMHIP_GENERATE_STREAMS")
+            if env_streams:
+                streams = max(1, int(env_streams))
         flags = [step % save_interval == 0 for step in range(timesteps)]
         if context is not None:
             context = context.to(eng.device)
@@ -400,10 +438,24 @@ class Pipeline(nn.Module):
             cs = self._copy_streams = []
         while len(cs) < n_lanes:
             cs.append(torch.cuda.Stream(device=eng.device))
-        ids, _ = self.generate_ids(context, B, timesteps, temperature, topk, flags, seed, image_base=image_base,
-                                   use_graph=use_graph, streams=streams, host=(host, cs))
-        for c in cs[:n_lanes]:
-            c.synchronize()                                  # every image has landed in the host buffer
+        try:
+            ids, _ = self.generate_ids(context, B, timesteps, temperature, topk, flags, seed, image_base=image_base,
+                                       use_graph=use_graph, streams=streams, host=(host, cs))
+        except BaseException:
+            # a lane failed: whatever the other lanes queued may still be writing into `host`; drain it, and never hand
+            # this buffer out again
+            _pinned_pool.discard(host)
+            try:
+                torch.cuda.synchronize(eng.device)
+            except Exception:
+                pass
+            raise
+        finally:
+            for c in cs[:n_lanes]:
+                try:
+                    c.synchronize()                          # every image has landed in the host buffer
+                except Exception:
+                    pass
         out = list(host)                                     # views of one pinned buffer; it is reused once all of them are gone
         return (out, ids) if return_ids else out
 

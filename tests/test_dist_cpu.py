@@ -24,6 +24,8 @@ def test_shard_range_is_a_partition():
 class FakePipe:
     """generate() returns images that encode (seed, global image index, step): what the real path guarantees"""
 
+    image_shape = (3, 4, 4)
+
     class TM:
         base_index = 0
 
@@ -39,13 +41,37 @@ class FakePipe:
         return out
 
 
+class FakePipeNoShape(FakePipe):
+    image_shape = None          # the fallback: ranks agree on the image shape through one extra all_gather
+
+
 def _worker(rank, world, port, n_prompts, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         prompts = [f"p{i}" for i in range(n_prompts)]
-        res = generate_sharded(FakePipe(), prompts, seed=7, timesteps=4, save_interval=2)
+        # count the collectives generate_sharded issues: exactly one gather per call
+        calls = {"gather": 0, "all_gather": 0}
+        real_gather, real_all_gather = dist.gather, dist.all_gather
+
+        def counting_gather(*a, **k):
+            calls["gather"] += 1
+            return real_gather(*a, **k)
+
+        def counting_all_gather(*a, **k):
+            calls["all_gather"] += 1
+            return real_all_gather(*a, **k)
+        dist.gather, dist.all_gather = counting_gather, counting_all_gather
+        try:
+            res = generate_sharded(FakePipe(), prompts, seed=7, timesteps=4, save_interval=2)
+            assert calls == {"gather": 1, "all_gather": 0}, calls
+            res2 = generate_sharded(FakePipeNoShape(), prompts, seed=7, timesteps=4, save_interval=2)
+            assert calls["gather"] == 2 and calls["all_gather"] == (1 if n_prompts < world else 0), calls
+            if rank == 0:
+                assert all(torch.equal(a, b) for a, b in zip(res, res2))
+        finally:
+            dist.gather, dist.all_gather = real_gather, real_all_gather
         lo, hi = shard_range(n_prompts, rank, world)
         local = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1)
         counts = [shard_range(n_prompts, r, world)[1] - shard_range(n_prompts, r, world)[0] for r in range(world)]

@@ -244,6 +244,7 @@ def test_hilo_stream_and_layernorm_fold_full_size(pipe512, monkeypatch):
             monkeypatch.delenv("PMHIP_LN_UNFOLD", raising=False)
             for k_, v_ in env.items():
                 monkeypatch.setenv(k_, v_)
+            pipe.invalidate_engines()                                      # the switches are read when a native handle is created
             res[mode] = pipe.tokens2logits(tok, None)
             ops.timing_reset(); ops.timing_enable(True)
             pipe.tokens2logits(tok, None)
@@ -263,5 +264,36 @@ def test_hilo_stream_and_layernorm_fold_full_size(pipe512, monkeypatch):
         assert errs["fold"] < BF16_LOGIT_MAXERR and errs["fold"] < 2.0 * errs["f32"] + 1e-3 and errs["unfold"] < 2.0 * errs["f32"] + 1e-3
         assert flips["fold"] <= 1.2 * flips["f32"] + 10 and flips["unfold"] <= 1.2 * flips["f32"] + 10
         assert ln["fold"][1] < 0.8 * ln["f32"][1]                          # the coefficient pass reads 2 of the 6 bytes per element
+        # a folded consumer over more rows than one launch may address (32-bit byte offsets: 2M rows at dim 512) is cut into
+        # launches of whole images; forced here with a cap of two images per launch: bit-identical to the single launch
+        monkeypatch.setenv("PMHIP_FOLD_MAX_ROWS", "2048")
+        pipe.invalidate_engines()
+        assert torch.equal(pipe.tokens2logits(tok[:5], None), res["fold"][:5])
+        b = pipe.generate_ids(None, 16, 4, 1.0, 5, [True] * 4, seed=3, use_graph=True, streams=1)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     finally:
+        monkeypatch.delenv("PMHIP_FOLD_MAX_ROWS", raising=False)
+        monkeypatch.delenv("PMHIP_HILO", raising=False)
+        monkeypatch.delenv("PMHIP_LN_UNFOLD", raising=False)
+        pipe.invalidate_engines()
         pipe.set_compute_dtype(torch.float32)
+
+
+def test_bf16_tower_wider_than_the_hilo_row_operators():
+    """dim = 1280 > 1024: the hi/lo row operators (one wave per row, the row in registers) do not serve it, so a bf16 tower of
+    that width keeps the fp32 residual stream + pmhip_layernorm (engine.hip kHiloMaxDim) instead of failing on its first
+    forward.  Checked against fp32-verify on the same weights."""
+    cfg = dict(ver2cfg["bench-text-24L-d768"], dim=1280, num_head=20, mlp_dim=5120, depth=2, context_dim=1280)
+    torch.manual_seed(0)
+    pipe = Pipeline(pm.Config(cfg), stage1_pretrained=False).to(dev()).eval()
+    g = torch.Generator().manual_seed(3)
+    tok = torch.randn(2, 1024, 32, generator=g).to(dev())
+    ctx = torch.randn(2, 77, 1280, generator=g).to(dev())
+    l32 = pipe.tokens2logits(tok, ctx)
+    pipe.set_compute_dtype(torch.bfloat16)
+    l16 = pipe.tokens2logits(tok, ctx)
+    l16_1 = pipe.tokens2logits(tok[:1], ctx[:1])
+    assert torch.isfinite(l16).all() and torch.equal(l16[:1], l16_1)
+    err = (l16 - l32).abs()
+    print(f"dim 1280 bf16 vs fp32 logits: max {float(err.max()):.5f} mean {float(err.mean()):.6f} (logits std {float(l32.std()):.3f})")
+    assert float(err.max()) < 0.05 and float(err.mean()) < 0.006

@@ -515,24 +515,99 @@ def test_full_size_inpaint_outpaint_against_oracle(vit_s):
             assert maxabs(n(img), img_o) < TOL
 
 
-def test_bf16_perf_mode_deviation_is_bounded(vit_s):
-    """bf16 mode is graded on throughput; its deviation from the fp32 path is measured and bounded here
-    (the reference under torch.autocast(bfloat16) flips 3.0 % of tokens)."""
-    x = (torch.rand(4, 3, 256, 256, generator=torch.Generator().manual_seed(100)) * 2 - 1).to(dev())
-    z32, _, idx32 = vit_s.encode(x)
-    rec32 = vit_s.decode(z32)
+# bf16 mode of the ViT towers against fp32-verify, measured on MI355X over seeds 100..103 at B = 4 and on the bench input at
+# B = 64 (round 4, hi/lo stream + folded LayerNorm): token agreement 0.9874-0.9893 (a count statistic: sigma 0.0017 at B = 4,
+# 0.0004 at B = 64), reconstruction mean abs deviation 0.0059-0.0063 with the SAME latent, max 0.36 (39 % of the pixels of this
+# random-weight decoder saturate at +-1, SURVEY.md 8(a) a9, so single pixels move a lot).  Bars: 2 sigma below / 10 % above.
+BF16_VIT_TOKEN_AGREE = {4: 0.984, 64: 0.9865}
+BF16_VIT_REC_MEAN_DEV = 0.0070
+BF16_VIT_REC_MAX_DEV = 0.60
+
+
+def _bf16_vit_stats(vit_s, x, chunk=8):
+    """(token agreement, mean / max |rec_bf16 - rec_fp32| decoding the SAME fp32 latent, the same with each mode's own
+    tokens).  fp32-verify runs in chunks (the exact-f32 matrix core path is 15x slower and is only the checker here)."""
+    z32, idx32, rec32 = [], [], []
+    for i in range(0, x.shape[0], chunk):
+        z, _, idx = vit_s.encode(x[i:i + chunk])
+        z32.append(z); idx32.append(idx); rec32.append(vit_s.decode(z))
+    z32, idx32, rec32 = torch.cat(z32), torch.cat(idx32), torch.cat(rec32)
     vit_s.set_compute_dtype(torch.bfloat16)
     try:
         z16, _, idx16 = vit_s.encode(x)
         rec16 = vit_s.decode(z32)
+        rec16_own = vit_s.decode(z16)
     finally:
         vit_s.set_compute_dtype(torch.float32)
     agree = float((idx16 == idx32).float().mean())
-    dev_mean = float((rec16 - rec32).abs().mean())
-    print(f"bf16 token agreement {agree:.4f}, reconstruction mean abs dev {dev_mean:.5f}")
-    assert agree > 0.90 and dev_mean < 0.03
+    d = (rec16 - rec32).abs()
+    return agree, float(d.mean()), float(d.max()), float((rec16_own - rec32).abs().mean())
+
+
+@pytest.mark.parametrize("B", [4, 64])
+def test_bf16_perf_mode_deviation_is_bounded(vit_s, B):
+    """bf16 mode is graded on throughput; its deviation from the fp32 path is measured and bounded here at the batch the
+    reconstruction bench times (BASELINE.json configs[1]: B = 64, bf16) and at B = 4, with bars two sigma from the
+    measured values (the reference under torch.autocast(bfloat16) flips 3.0 % of tokens)."""
+    seed = 100 if B == 4 else 0
+    x = (torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(seed)) * 2 - 1).to(dev())
+    agree, dev_mean, dev_max, dev_own = _bf16_vit_stats(vit_s, x)
+    print(f"B={B}: bf16 token agreement {agree:.4f}, reconstruction |dev| mean {dev_mean:.5f} max {dev_max:.4f} (same latent), "
+          f"mean {dev_own:.5f} (own tokens)")
+    assert agree >= BF16_VIT_TOKEN_AGREE[B], agree
+    assert dev_mean <= BF16_VIT_REC_MEAN_DEV and dev_max <= BF16_VIT_REC_MAX_DEV, (dev_mean, dev_max)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert vit_s.compute_dtype == torch.bfloat16
+
+
+def test_paintmindv1_preset_sample_step_and_fast_path():
+    """The reference's only pipeline preset (config.py:70-82, the default of factory.py:6): 12L / d1024 / 16 heads with T5-L
+    features of width 1024, so context_proj is nn.Identity (stage2/transformer.py:58).  The T5 tower itself is a pretrained
+    third-party model that is not in this image: the synthetic (B, 77, 1024) embedder stands in for it.
+    (a) fp32-verify: logits within 1e-3 of the numpy oracle, one sample step (generate.py:159-181) with topk=1: kept ids equal
+        the oracle's arg-max except at near-ties, image of the oracle's predictions within 1e-3;
+    (b) bf16: the default generate() path (graph replay + two lanes) is bit-identical to the eager single-stream loop."""
+    from paintmind_amd.config import ver2cfg
+    from paintmind_amd.modules.encoder import SyntheticTextEmbedder
+    scfg, vcfg = ver2cfg["paintmindv1"], ver2cfg["vit-s-vqgan"]
+    torch.manual_seed(5)
+    pipe = Pipeline(pm.Config(scfg), stage1_pretrained=False, text_model=SyntheticTextEmbedder(1024)).eval()
+    assert isinstance(pipe.transformer.context_proj, torch.nn.Identity)
+    p = {k: v.detach().numpy() for k, v in pipe.state_dict().items() if not k.startswith("text_model")}
+    pipe = pipe.to(dev())
+    N, V = pipe.num_tokens, vcfg["n_embed"]
+    g = torch.Generator().manual_seed(9)
+    ids0 = torch.randint(0, V, (1, N), generator=g)
+    ids0[torch.rand(1, N, generator=g) < 0.6] = V
+    ctx = pipe.text_model(["a prompt"]).cpu()
+    assert ctx.shape == (1, 77, 1024)
+    ocfg = dict(scfg, context_dim=1024)
+    logits = pipe.tokens2logits(pipe.ids2tokens(ids0.to(dev())), ctx.to(dev()))
+    ref = O.cond_transformer(O.ids2tokens(ids0.numpy(), p), ctx.numpy(), p, ocfg)
+    assert maxabs(n(logits), ref) < TOL
+    ids1, img1 = pipe.sample(ids0.to(dev()), np.float64(0.3), text=ctx.to(dev()), topk=1, temperature=1.0)
+    top2 = -np.sort(-ref, axis=-1)[..., :2]
+    pred_ref = ref.argmax(-1)
+    got = n(ids1)
+    kept = (ids0.numpy() == V) & (got != V)
+    bad = kept & (got != pred_ref)
+    assert np.all((top2[..., 0] - top2[..., 1])[bad] < 1e-4), int(bad.sum())
+    assert int((got == V).sum()) == max(int(0.3 * N), 1)
+    vq_p = {k[len("vqgan."):]: v for k, v in p.items() if k.startswith("vqgan.")}
+    img_ref = O.vqgan_decode_indices(pred_ref, vq_p, vcfg)
+    assert maxabs(n(pipe.vqgan.decode_from_indice(torch.from_numpy(pred_ref).to(dev()))), img_ref) < TOL
+    if not bad.any() and np.array_equal(n(ids1)[ids0.numpy() != V], ids0.numpy()[ids0.numpy() != V]):
+        assert img1.shape == (1, 3, 256, 256)
+    # (b) the call a user of the preset makes, in bf16
+    pipe.set_compute_dtype(torch.bfloat16)
+    text = [f"prompt {i}" for i in range(8)]
+    eager = pipe.generate(text, timesteps=6, seed=11, return_ids=True, use_graph=False, streams=1)
+    for _ in range(3):                                          # eager warm-up of the graph path, capture, replay
+        fast = pipe.generate(text, timesteps=6, seed=11, return_ids=True)
+        assert len(fast[0]) == len(eager[0]) == 3
+        assert torch.equal(fast[1], eager[1])
+        assert all(torch.equal(a, b) for a, b in zip(fast[0], eager[0]))
+    assert torch.isfinite(eager[0][-1]).all() and int((eager[1] == V).sum(1).max()) == 1
 
 
 @pytest.mark.parametrize("name,B", [("bench-text-24L-d768", 2), ("bench-text-24L-d1024-512px", 1)])
@@ -589,3 +664,46 @@ def test_tiny_pipeline_forward_loss_golden(tiny_pipe):
         assert 0.5 * np.log(64) < float(pipe(t(tf["img"]), None)) < 2 * np.log(64)
     finally:
         pipe.text_model = text_model
+
+
+def test_generate_lane_failure_does_not_poison_the_host_pool(tiny_pipe, monkeypatch):
+    """Pipeline.generate() with two lanes: when one lane raises, the call waits for the other lane and for every copy stream
+    before the exception leaves, the pinned buffer of the failed call is never handed out again, and the next call is correct.
+    PMHIP_GENERATE_STREAMS=1 is the process-wide opt-out of the lane default."""
+    from paintmind_amd import generate as G
+    pipe, _, _ = tiny_pipe
+    text = [f"p{i}" for i in range(8)]
+    pipe.set_compute_dtype(torch.bfloat16)
+    try:
+        want = pipe.generate(text, timesteps=4, seed=5, use_graph=False, streams=1)
+        want = [w.clone() for w in want]
+        pipe.generate(text, timesteps=4, seed=5, streams=2)
+        lanes = pipe._lanes(2)
+        eng1 = lanes[1][0]
+        real = eng1.generate
+        seen = []
+
+        def boom(*a, **k):
+            seen.append(k.get("host"))
+            raise RuntimeError("injected lane failure")
+        monkeypatch.setattr(eng1, "generate", boom)
+        with pytest.raises(RuntimeError, match="injected lane failure"):
+            pipe.generate(text, timesteps=4, seed=5, streams=2)
+        failed_host = seen[0][0]
+        assert all(b.untyped_storage().data_ptr() != failed_host.untyped_storage().data_ptr() for b in G._pinned_pool.bufs)
+        monkeypatch.setattr(eng1, "generate", real)
+        got = pipe.generate(text, timesteps=4, seed=5, streams=2)
+        assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+        assert got[0].untyped_storage().data_ptr() != failed_host.untyped_storage().data_ptr()
+        monkeypatch.setenv("PMHIP_GENERATE_STREAMS", "1")
+        calls = []
+        real_ids = pipe.generate_ids
+
+        def spy(*a, **k):
+            calls.append(k.get("streams"))
+            return real_ids(*a, **k)
+        monkeypatch.setattr(pipe, "generate_ids", spy)
+        got = pipe.generate(text, timesteps=4, seed=5)
+        assert calls == [1] and all(torch.equal(a, b) for a, b in zip(got, want))
+    finally:
+        pipe.set_compute_dtype(torch.float32)

@@ -216,6 +216,40 @@ def test_layernorm_fold_consumers():
     assert rel_err(hid[:, :1368], ref) < 3e-2 and rel_err(hid2[:, :1368], ref) < 3e-2 and np.all(hid[:, 1368:] == 0)
 
 
+@pytest.mark.parametrize("offset,massive", [(0.0, 0), (2.0, 0), (2.0, 3), (50.0, 3)])
+def test_layernorm_fold_accuracy_with_row_offsets_and_massive_channels(offset, massive):
+    """The folded LayerNorm normalises bf16(x) (the hi plane): x is rounded BEFORE the mean is subtracted, so a row whose common
+    offset is large against its spread loses 2^-9 |x| / std per element where the unfolded pmhip_layernorm_hilo (statistics and
+    normalisation of hi + lo in fp32, one rounding of the result) loses 2^-9 |LN(x)|.  Measured here for rows with
+    mean = offset x std and `massive` outlier channels of 100 x std -- the shape of trained transformers' activations; the seeded
+    random-init weights of the parity suite have offset ~ 0.  Bars: the fold stays within 1.5x of the unfolded kernel's error up
+    to offset 2; at offset 50 its error must stay inside the rounding model 2^-9 * offset (a regression detector: such
+    checkpoints should run with PMHIP_LN_UNFOLD=1)."""
+    M, D, N = 2048, 512, 1536
+    bf = torch.bfloat16
+    x = rnd(M, D) + offset * (1.0 + 0.2 * rnd(M, 1))
+    if massive:
+        x[:, :massive] += 100.0 * np.sign(rnd(1, massive))
+    hi, lo = ops.split_hilo(t(x))
+    gamma, beta = 1 + 0.3 * rnd(D), 0.2 * rnd(D)
+    x64 = n(ops.join_hilo(hi, lo)).astype(np.float64)
+    y64 = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * gamma + beta
+    w1 = bf16_round(rnd(N, D, scale=D ** -0.5))
+    want = y64 @ w1.astype(np.float64).T
+    wg, c, d = packing.ln_fold(t(w1), t(gamma), t(beta))
+    got = n(ops.gemm_ln(hi, wg, ops.ln_coef(hi), c, d, out_dtype=torch.float32))
+    unf = n(ops.gemm(ops.layernorm_hilo(hi, lo, t(gamma), t(beta), out_dtype=bf), t(w1, bf), out_dtype=torch.float32))
+    scale = np.abs(want).std()
+    e_fold, e_unf = np.abs(got - want).mean() / scale, np.abs(unf - want).mean() / scale
+    print(f"offset {offset} x std, {massive} massive channels: mean |err| / std(out): folded {e_fold:.5f}, unfolded {e_unf:.5f}")
+    if offset <= 2.0 and not massive:
+        assert e_fold < 1.5 * e_unf + 1e-3, (e_fold, e_unf)
+    # rounding model: per-element error of bf16(x) relative to the row's spread, averaged by the K = 512 contraction
+    rel = 2.0 ** -9 * max(1.0, np.abs(x).mean() / x.std(1).mean())
+    assert e_fold < 4.0 * rel + 4e-3, (e_fold, rel)
+    assert e_unf < 6e-3, e_unf
+
+
 def test_gemm_is_transpose_correct_on_asymmetric_data():
     """A = identity-like selector, W asymmetric: catches a swapped (m,n) in the MFMA output mapping."""
     M = N = K = 128

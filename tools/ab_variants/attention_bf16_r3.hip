@@ -388,15 +388,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
 
     int hs = 0;
     const int nh_full = 2 * (Nkv / KT);                      // half-tiles that lie in full tiles
-    // A context without a ragged tile (self-attention: every stage-2 / ViT launch of the decode loop) runs ALL its half-tiles,
-    // the last two included, through the steady-state step.  Past the end `step` still computes S^T(h+1) and prefetches K(h+2):
-    // both address ring stage ntiles % 3, which still holds tile ntiles - 3 (no DMA is issued past the last tile), i.e. finite
-    // scores of keys that were already folded into the running max, so the growth check cannot fire on them and nothing they
-    // produce is consumed: 16 wasted MFMAs per workgroup-wave instead of two full-wait slow steps with their unconditional
-    // rescale (round 4; the last tile was 6 % of the half-tiles at N = 1024 and ran at less than half the steady-state speed).
-    const bool all_steady = (Nkv % KT) == 0 && ntiles >= 3;
-    const int steady_end = all_steady ? nhalves - 1 : min(nhalves - 3, nh_full - 2);   // one bound: the loop's shape is unchanged
-    for (; hs < steady_end; hs += 2) {                       // steady state
+    for (; hs + 3 < nhalves && hs + 2 < nh_full; hs += 2) {  // steady state
         step(Y, sA, sB, hs);
         step(N, sB, sA, hs + 1);
     }
