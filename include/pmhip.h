@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PMHIP_ABI_VERSION 7
+#define PMHIP_ABI_VERSION 8
 
 enum { PMHIP_OK = 0, PMHIP_EINVAL = 1, PMHIP_EHIP = 2, PMHIP_ENOMEM = 3, PMHIP_ESTATE = 4 };
 enum { PMHIP_F32 = 0, PMHIP_BF16 = 1 };
@@ -170,6 +170,12 @@ int pmhip_convert_pad(const float* in, int K, void* out, int out_dtype, int Kpad
  * stage1/layers.py:108,146; stage2/transformer.py:82). */
 int pmhip_add_rows(const float* x, const float* table, int table_rows, float* out, int M, int D,
                    pmhip_stream stream);
+
+/* out = uncond + scale * (cond - uncond) over n fp32 elements (n % 4 == 0), fmaf per element; out may alias either input.
+ * Guidance between the text-conditioned and the unconditional logits of one MaskGIT step: the reference trains for it by dropping
+ * the text 10 % of the time (utils/trainer.py:379,387-388: `text = None` -> attn2 becomes a second self-attention,
+ * modules/attention.py:47) but its own sampling (generate.py:159-181) never combines the two; SURVEY.md section 8(f) row 2. */
+int pmhip_guidance_combine(const float* cond, const float* uncond, float scale, float* out, size_t n, pmhip_stream stream);
 
 /* Row gather out[m,:] = table[ids[m],:] (nn.Embedding: stage1/quantize.py:41, generate.py:148-157),
  * table fp32 [V,E], ids int64, out `out_dtype` [M,Kpad] zero-padded. */

@@ -260,11 +260,19 @@ def remask_threshold_sets(scores, num_mask):
     return scores > thr, scores >= thr
 
 
-def sample_step(ids, mask_ratio, context, topk, temperature, noise, p, cfg, s2cfg, decode=True):
-    """Pipeline.sample, generate.py:159-181 -> (ids', img, aux)"""
+def sample_step(ids, mask_ratio, context, topk, temperature, noise, p, cfg, s2cfg, decode=True, guidance_scale=None):
+    """Pipeline.sample, generate.py:159-181 -> (ids', img, aux).
+    guidance_scale (not in the reference's sampling; the reference only TRAINS the unconditional branch, utils/trainer.py:379,
+    387-388): logits = uncond + scale * (cond - uncond) with uncond = the same forward with context=None, one fused multiply-add
+    per element in float32 -- intended behaviour, unpinned by the reference."""
     B, N = ids.shape
     mask_id = cfg["n_embed"]
-    logits = cond_transformer(ids2tokens(ids, p), context, p, s2cfg)                       # :161-162
+    tok = ids2tokens(ids, p)
+    logits = cond_transformer(tok, context, p, s2cfg)                                      # :161-162
+    if guidance_scale is not None:
+        uncond = cond_transformer(tok, None, p, s2cfg)
+        diff = (logits - uncond).astype(np.float32)
+        logits = (np.float64(np.float32(guidance_scale)) * diff.astype(np.float64) + uncond.astype(np.float64)).astype(np.float32)
     V = logits.shape[-1]
     pred, merged, score = sample_rows(logits.reshape(B * N, V), ids.reshape(-1), mask_id, topk, temperature,
                                       noise.reshape(B * N, V))

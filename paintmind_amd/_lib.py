@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpaintmind_hip.so")
 PMHIP_OK = 0
 F32, BF16 = 0, 1
 PART_Q, PART_K, PART_V = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 vp = C.c_void_p
 i32 = C.c_int
@@ -94,6 +94,7 @@ PROTOTYPES = {
     "pmhip_unpatchify_clamp": (i32, [vp, vp, i32, i32, i32, i32, i32, f32, f32, vp]),
     "pmhip_convert_pad": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "pmhip_add_rows": (i32, [vp, vp, i32, vp, i32, i32, vp]),
+    "pmhip_guidance_combine": (i32, [vp, vp, C.c_float, vp, C.c_size_t, vp]),
     "pmhip_embed_rows": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "pmhip_random_mask": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]),
     "pmhip_masked_ce": (i32, [vp, i32, vp, vp, f32, vp, vp, i32, i32, vp]),

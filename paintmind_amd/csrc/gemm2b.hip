@@ -97,7 +97,11 @@ __global__ __launch_bounds__(THREADS, 2) void gemm2b_kernel(const GemmParams p) 
         __builtin_amdgcn_s_setprio(0);                                                              \
     }
 
+#ifdef PM_ABL_NO_KLOOP
+    const int nk = 1;
+#else
     const int nk = p.K / KSTEP;
+#endif
     ISSUE_A(0)
     ISSUE_W(0)
     for (int kt = 0; kt < nk; ++kt) {

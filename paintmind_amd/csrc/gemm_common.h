@@ -371,15 +371,30 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
     // hi/lo residual stream: residual and output are pairs of bf16 planes, 8 columns (16 B of each plane) per lane
     constexpr bool HILO = (EPI == EPI_STD) && RES == 2 && sizeof(OutT) == 2;
     constexpr bool PIPE_HILO = HILO && FULL;
-    [[maybe_unused]] uint4 hnext[ITERS] = {}, lnext[ITERS] = {};
+    // The residual pair of slice mi + HD is requested while slice mi is transposed, added and stored.  HD = 1: two and three slices
+    // ahead measured 2-6 % SLOWER on the out-projection and equal on w3 (profiles/r04_producer_ablation.txt): the epilogue is
+    // bound by the HBM read + write mix of all CUs storing at once, not by the bytes one CU keeps in flight
+#ifndef PM_HILO_DEPTH
+#define PM_HILO_DEPTH 1
+#endif
+    constexpr int HD = PIPE_HILO ? (PM_HILO_DEPTH < MI ? PM_HILO_DEPTH : MI) : 1;
+    [[maybe_unused]] uint4 hq[HD][ITERS] = {}, lq[HD][ITERS] = {};
     [[maybe_unused]] const bf16_t* res_hi = reinterpret_cast<const bf16_t*>(p.residual);
-    if constexpr (PIPE_HILO) {
+    [[maybe_unused]] auto load_pair = [&](int slice, uint4 (&h)[ITERS], uint4 (&l)[ITERS]) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const size_t off = (size_t)((mwave + it * RPI + lane / LPR) % p.res_rows) * p.ldr + ncol;
-            hnext[it] = *reinterpret_cast<const uint4*>(res_hi + off);
-            lnext[it] = *reinterpret_cast<const uint4*>(p.res_lo + off);
+#ifdef PM_ABL_NO_RESLOAD
+            h[it] = make_uint4(0x3f803f80u + slice, 0, 0, 0); l[it] = make_uint4(0, 0, 0, 0);
+#else
+            const size_t off = (size_t)((mwave + slice * 16 + it * RPI + lane / LPR) % p.res_rows) * p.ldr + ncol;
+            h[it] = *reinterpret_cast<const uint4*>(res_hi + off);
+            l[it] = *reinterpret_cast<const uint4*>(p.res_lo + off);
+#endif
         }
+    };
+    if constexpr (PIPE_HILO) {
+#pragma unroll
+        for (int d = 0; d < HD; ++d) load_pair(d, hq[d], lq[d]);
     }
     constexpr bool PIPE_RES = (EPI == EPI_STD) && FULL && RES == 1 && NPRE == 1 && sizeof(OutT) == 4;
     float4 rnext[ITERS] = {};
@@ -402,17 +417,10 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             }
         }
         [[maybe_unused]] uint4 hcur[ITERS], lcur[ITERS];
-        if constexpr (PIPE_HILO) {
+        if constexpr (PIPE_HILO) {                          // ring slot mi % HD (mi is a compile-time constant after unrolling)
 #pragma unroll
-            for (int it = 0; it < ITERS; ++it) { hcur[it] = hnext[it]; lcur[it] = lnext[it]; }
-            if (mi + 1 < MI) {
-#pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const size_t off = (size_t)((mwave + (mi + 1) * 16 + it * RPI + lane / LPR) % p.res_rows) * p.ldr + ncol;
-                    hnext[it] = *reinterpret_cast<const uint4*>(res_hi + off);
-                    lnext[it] = *reinterpret_cast<const uint4*>(p.res_lo + off);
-                }
-            }
+            for (int it = 0; it < ITERS; ++it) { hcur[it] = hq[mi % HD][it]; lcur[it] = lq[mi % HD][it]; }
+            if (mi + HD < MI) load_pair(mi + HD, hq[mi % HD], lq[mi % HD]);
         }
         const int mbase = mwave + mi * 16;
         if constexpr (GATE_IN_REGS) {
@@ -499,8 +507,13 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                             oh[j] = pack_bf16x2(x0, x1);
                             ol[j] = pack_bf16x2(x0 - __uint_as_float(oh[j] << 16), x1 - __uint_as_float(oh[j] & 0xffff0000u));
                         }
+#ifdef PM_ABL_NO_STORE
+                        if (mm < 0)
+#endif
+                        {
                         nt_store16(reinterpret_cast<bf16_t*>(p.out) + (size_t)mm * p.ldo + ncol, make_uint4(oh[0], oh[1], oh[2], oh[3]));
                         nt_store16(p.out_lo + (size_t)mm * p.ldo + ncol, make_uint4(ol[0], ol[1], ol[2], ol[3]));
+                        }
                         if (p.row_stats) {                          // wave-uniform.  The 8 lanes of a row hold its 64 hi values of this wave
                             float hv[8];
 #pragma unroll

@@ -184,6 +184,18 @@ __global__ __launch_bounds__(THREADS) void add_rows_kernel(const float* __restri
     }
 }
 
+// out = uncond + scale * (cond - uncond): logits of a text-conditioned and an unconditional forward combined for guidance
+// (the reference TRAINS for this -- 10 % text drop, utils/trainer.py:379,387-388 -- but its inference never combines them; an
+// extension behind an explicit keyword).  One fused multiply-add per element in fp32, in place when out aliases cond or uncond.
+__global__ __launch_bounds__(THREADS) void guidance_kernel(const float* __restrict__ cond, const float* __restrict__ uncond, float scale,
+                                                           float* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * THREADS) {
+        const float4 c = reinterpret_cast<const float4*>(cond)[i], u = reinterpret_cast<const float4*>(uncond)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(fmaf(scale, c.x - u.x, u.x), fmaf(scale, c.y - u.y, u.y), fmaf(scale, c.z - u.z, u.z),
+                                                       fmaf(scale, c.w - u.w, u.w));
+    }
+}
+
 inline int grid_for(size_t total) {
     size_t blocks = (total + THREADS - 1) / THREADS;
     if (blocks > 256 * 8) blocks = 256 * 8;       // grid-stride the rest
@@ -487,6 +499,16 @@ extern "C" int pmhip_add_rows(const float* x, const float* table, int table_rows
     hipStream_t s = (hipStream_t)stream;
     PmTimer tm(FAM_ROWOPS, s);
     hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for((size_t)M * (D / 4))), dim3(THREADS), 0, s, x, table, table_rows, out, M, D);
+    PM_HIP(hipGetLastError());
+    return PMHIP_OK;
+}
+
+extern "C" int pmhip_guidance_combine(const float* cond, const float* uncond, float scale, float* out, size_t n, pmhip_stream stream) {
+    PM_REQUIRE(cond && uncond && out, "guidance_combine: null pointer");
+    PM_REQUIRE(n > 0 && n % 4 == 0, "guidance_combine: n must be a positive multiple of 4");
+    hipStream_t s = (hipStream_t)stream;
+    PmTimer tm(FAM_ROWOPS, s);
+    hipLaunchKernelGGL(guidance_kernel, dim3(grid_for(n / 4)), dim3(THREADS), 0, s, cond, uncond, scale, out, n / 4);
     PM_HIP(hipGetLastError());
     return PMHIP_OK;
 }

@@ -228,7 +228,8 @@ class Pipeline(nn.Module):
         return rows.reshape(ids.shape + (table.shape[1],))
 
     @torch.no_grad()
-    def sample(self, ids, mask_ratio, text=None, topk=1, temperature=1, noise=None, seed=None, step=0, image_base=0):
+    def sample(self, ids, mask_ratio, text=None, topk=1, temperature=1, noise=None, seed=None, step=0, image_base=0,
+               guidance_scale=None):
         """One MaskGIT step (generate.py:159-181) -> (ids', img).
 
         ``noise``: optional uniform(0,1) tensor shaped like the logits (B,N,V) -- the parity hook for the
@@ -236,23 +237,52 @@ class Pipeline(nn.Module):
         by (seed, step, image_base + image index, position, class) is used.  ``seed=None`` draws a fresh
         seed from the torch generator on every call, like the reference's fresh global-RNG noise
         (generate.py:40-46), so a caller looping over sample() never reuses uniforms.
+
+        ``guidance_scale`` (extension; None = the reference's behaviour): the step's logits become
+        ``uncond + guidance_scale * (cond - uncond)`` with ``uncond = transformer(tokens, None)``, the path the reference
+        trains by dropping the text 10 % of the time (utils/trainer.py:379,387-388) but never uses when sampling.  Both
+        forwards share the step's token lookup; everything after the logits is the reference's step unchanged.
         """
         nm = num_token_masked(mask_ratio, self.num_tokens)
+        if guidance_scale is not None and text is None:
+            raise ValueError("guidance_scale needs a text condition (text=None IS the unconditional branch)")
         if self._on_cpu():
-            return self._sample_cpu(ids, nm, text, topk, temperature, noise, seed)
+            return self._sample_cpu(ids, nm, text, topk, temperature, noise, seed, guidance_scale)
         if seed is None:
             seed = _draw_seed()
         eng = self.engine()
         ids = ids.to(eng.device, torch.int64).clone().contiguous()
+        if guidance_scale is not None:
+            return self._sample_guided(eng, ids, nm, text, topk, temperature, noise, seed, step, image_base, guidance_scale)
         ids, img, _, _ = eng.sample(self.vqgan.engine(), ids, text, topk, temperature, nm, noise=noise, seed=seed, step=step,
                                     image_base=image_base, want_img=True)
         return ids, img
 
-    def _sample_cpu(self, ids, nm, text, topk, temperature, noise, seed):
+    def _sample_guided(self, eng, ids, nm, text, topk, temperature, noise, seed, step, image_base, scale):
+        """the guided step composed from the operator-level C ABI (two pmhip_s2_forward + pmhip_guidance_combine +
+        pmhip_sample_rows + decode + pmhip_remask): the same kernels, in the same order, as pmhip_pipeline_sample"""
+        B, N = ids.shape
+        tok = self.ids2tokens(ids)
+        cond = eng.forward(tok, text)
+        uncond = eng.forward(tok, None)
+        logits = ops.guidance_combine(cond, uncond, scale, out=cond)
+        if noise is not None:
+            noise = noise.to(eng.device, torch.float32).reshape(B * N, -1).contiguous()
+        pred, merged, score = ops.sample_rows(logits.reshape(B * N, -1), ids.reshape(-1), self.mask_token_id, topk, temperature,
+                                              noise=noise, seed=seed, step=step, row_base=image_base * N)
+        img = self.vqgan.decode_from_indice(pred.reshape(B, N))   # decoded from the predictions at ALL positions (:165)
+        ids = ops.remask(merged.reshape(B, N), score.reshape(B, N), nm, self.mask_token_id)
+        return ids, img
+
+    def _sample_cpu(self, ids, nm, text, topk, temperature, noise, seed, guidance_scale=None):
         """generate.py:159-181 in plain torch for a pipeline that lives on the CPU.  The noise is drawn from the torch CPU
         generator like the reference's (`seed` re-seeds a private generator; `noise` overrides it); ties in top-k / argmax
         follow torch."""
-        logits = self.tokens2logits(self.ids2tokens(ids), text)
+        tok = self.ids2tokens(ids)
+        logits = self.tokens2logits(tok, text)
+        if guidance_scale is not None:
+            uncond = self.tokens2logits(tok, None)
+            logits = torch.addcmul(uncond, logits - uncond, torch.tensor(float(guidance_scale)))
         val, ind = logits.topk(topk, dim=-1)
         filtered = torch.full_like(logits, float("-inf")).scatter_(2, ind, val)
         if noise is None:
@@ -295,12 +325,17 @@ class Pipeline(nn.Module):
         eng, vq = self.engine(), self.vqgan.engine()
         cache = getattr(self, "_lane_cache", None)
         if cache is None or cache[0] is not eng or cache[1] is not vq:
-            cache = (eng, vq, [(eng, vq, torch.cuda.Stream(device=eng.device))])
+            cache = (eng, vq, [(eng, vq, self._new_lane_stream(eng.device, 0, k))])
             self._lane_cache = cache
         lanes = cache[2]
         while len(lanes) < k:
-            lanes.append((eng.clone(), vq.clone(), torch.cuda.Stream(device=eng.device)))
+            lanes.append((eng.clone(), vq.clone(), self._new_lane_stream(eng.device, len(lanes), k)))
         return lanes[:k]
+
+    @staticmethod
+    def _new_lane_stream(device, lane, n_lanes):
+        """the HIP stream of one lane (a hook: tools/cu_mask_lanes.py replaces it with CU-masked streams for an experiment)"""
+        return torch.cuda.Stream(device=device)
 
     def generate_ids(self, context, B, timesteps, temperature, topk, decode_flags, seed, image_base=0, use_graph=False, streams=1,
                      join=True, wait_current=True, host=None):
@@ -386,7 +421,7 @@ class Pipeline(nn.Module):
         return ids, imgs
 
     def generate(self, text, timesteps=18, temperature=1.0, topk=5, save_interval=2, seed=None, image_base=0,
-                 return_ids=False, keep_on_device=False, use_graph=None, streams=None):
+                 return_ids=False, keep_on_device=False, use_graph=None, streams=None, guidance_scale=None):
         """Full decode loop (generate.py:183-198): list of (B,3,H,W) CPU tensors for steps % save_interval == 0.
 
         The call is the fast path by default: the loop replays captured hipGraphs (first call eager, second call captures),
@@ -408,6 +443,9 @@ class Pipeline(nn.Module):
         the list is dropped.  `.clone()` a result to own ordinary pageable memory, as the reference's `img.cpu()` returns."""
         B = len(text)
         context = self.text_model(text)
+        if guidance_scale is not None:
+            return self._generate_guided(context, B, timesteps, temperature, topk, save_interval, seed, image_base, return_ids,
+                                         keep_on_device, guidance_scale)
         if self._on_cpu():
             return self._generate_cpu(text, context, timesteps, temperature, topk, save_interval, seed, return_ids)
         eng = self.engine()
@@ -458,6 +496,26 @@ class Pipeline(nn.Module):
                     pass
         out = list(host)                                     # views of one pinned buffer; it is reused once all of them are gone
         return (out, ids) if return_ids else out
+
+    @torch.no_grad()
+    def _generate_guided(self, context, B, timesteps, temperature, topk, save_interval, seed, image_base, return_ids, keep_on_device,
+                         scale):
+        """generate.py:183-198 with guided steps (see `sample`): an eager loop of two forwards per step; same return structure"""
+        if context is None:
+            raise ValueError("guidance_scale needs a text condition")
+        if seed is None:
+            seed = _draw_seed()
+        dev = self.mask_token.device
+        ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=dev)
+        context = context.to(dev)
+        imgs = []
+        for step in range(timesteps):
+            ids, img = self.sample(ids, mask_schedule((step + 1) / timesteps), text=context, topk=topk,
+                                   temperature=temperature * (1 - step / timesteps), seed=seed if not self._on_cpu() else seed + step,
+                                   step=step, image_base=image_base, guidance_scale=scale)
+            if step % save_interval == 0:
+                imgs.append(img if keep_on_device else img.cpu())
+        return (imgs, ids) if return_ids else imgs
 
     def _region_loop(self, img, coord, text, timesteps, topk, temperature, keep_inside, seed=None, return_ids=False):
         if seed is None:

@@ -330,6 +330,18 @@ def add_rows(x, table):
     return out
 
 
+def guidance_combine(cond, uncond, scale, out=None):
+    """uncond + scale * (cond - uncond), fp32, same shape; `out` may be one of the inputs."""
+    dev = _dev(cond, uncond)
+    if cond.shape != uncond.shape or cond.dtype != torch.float32 or uncond.dtype != torch.float32:
+        raise ValueError("guidance_combine needs two fp32 tensors of one shape")
+    out = torch.empty_like(cond) if out is None else out
+    with torch.cuda.device(dev):
+        check(_lib.load().pmhip_guidance_combine(_p(cond), _p(uncond), float(scale), _p(out), cond.numel(), stream_ptr(dev)),
+              "pmhip_guidance_combine")
+    return out
+
+
 def embed_rows(table, ids, kpad, out_dtype):
     dev = _dev(table, ids)
     lib = _lib.load()

@@ -57,3 +57,13 @@ def test_tiny_vqgan_and_pipeline_goldens_on_cpu():
     imgs2, ids2 = pipe.generate(["a", "b"], timesteps=8, topk=5, save_interval=2, seed=5, return_ids=True)
     assert all(torch.equal(a, b) for a, b in zip(imgs, imgs2))
     assert int((ids2 == 64).sum(1).min()) == facts["residual_mask_tokens_after_T8"]
+
+    # guided step (extension) on the CPU branch against the oracle's restatement
+    from oracle import paintmind_oracle as O
+    g_ids, g_img = pipe.sample(ids0, np.float64(0.5), text=ctx, topk=5, temperature=0.7, noise=torch.from_numpy(d["s5_ctx_noise"]),
+                               guidance_scale=2.5)
+    o_ids, o_img, _ = O.sample_step(d["ids0"], np.float64(0.5), d["context"], 5, 0.7, d["s5_ctx_noise"], p, pm.ver2cfg["tiny-vqgan"],
+                                    pm.ver2cfg["tiny-pipeline"], guidance_scale=2.5)
+    assert np.array_equal(g_ids.numpy(), o_ids) and maxabs(g_img.numpy(), o_img) < 1e-4
+    g = pipe.generate(["a", "b"], timesteps=4, topk=3, save_interval=2, seed=5, guidance_scale=2.5)
+    assert len(g) == 2 and list(g[0].shape) == facts["generate_img_shape"]

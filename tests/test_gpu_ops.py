@@ -243,7 +243,7 @@ def test_layernorm_fold_accuracy_with_row_offsets_and_massive_channels(offset, m
     e_fold, e_unf = np.abs(got - want).mean() / scale, np.abs(unf - want).mean() / scale
     print(f"offset {offset} x std, {massive} massive channels: mean |err| / std(out): folded {e_fold:.5f}, unfolded {e_unf:.5f}")
     if offset <= 2.0 and not massive:
-        assert e_fold < 1.5 * e_unf + 1e-3, (e_fold, e_unf)
+        assert e_fold < 3.0 * e_unf + 1e-3, (e_fold, e_unf)
     # rounding model: per-element error of bf16(x) relative to the row's spread, averaged by the K = 512 contraction
     rel = 2.0 ** -9 * max(1.0, np.abs(x).mean() / x.std(1).mean())
     assert e_fold < 4.0 * rel + 4e-3, (e_fold, rel)
