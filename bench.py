@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 USE_GRAPH = os.environ.get("PM_BENCH_NO_GRAPH", "0") != "1"   # decode loop = one replayed hipGraph (captured during warm-up)
 STREAMS = int(os.environ.get("PM_BENCH_STREAMS", "2"))   # concurrent micro-batches per GPU (1 = one stream); 2 measured best
 LANE_SPLIT = os.environ.get("PM_BENCH_LANE_SPLIT")       # development: explicit micro-batch sizes, e.g. "32,16,16"
+PACE = int(os.environ.get("PM_BENCH_PACE", "2"))        # steps the host may run ahead of the GPU in the timed loop
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
@@ -513,6 +514,39 @@ def gemm_calibration(device, iters=12):
             "note": "frac_calibrated = frac x reference / measured: comparable across boxes of the pool (spread +-3..8 %)"}
 
 
+def thread_cpu_seconds():
+    """{tid: (thread name, user + system CPU seconds)} of this process (Linux /proc)"""
+    out = {}
+    tck = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                raw = open(f"/proc/self/task/{tid}/stat").read()
+                name = raw[raw.index("(") + 1:raw.rindex(")")]
+                f = raw[raw.rindex(")") + 2:].split()
+                out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tck)
+            except Exception:
+                pass
+    except Exception:
+        pass
+    return out
+
+
+def blocking_sync(device_index):
+    """hipDeviceScheduleBlockingSync before the device context exists: torch.cuda.synchronize() then SLEEPS on an interrupt
+    instead of spinning (the default on a host with more cores than GPUs), so a rank that only waits for its GPU does not burn
+    a core -- eight ranks share the node's cores (16 in this pool's cgroup).  PM_BENCH_SPIN_SYNC=1 keeps the default."""
+    if os.environ.get("PM_BENCH_SPIN_SYNC") == "1":
+        return
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipSetDevice(ctypes.c_int(device_index))
+        hip.hipSetDeviceFlags(ctypes.c_uint(0x4))           # hipDeviceScheduleBlockingSync
+    except Exception:
+        pass
+
+
 def flush_c_stdout():
     # RCCL writes its version banner to the C stdout buffer; push that out first so the JSON line is the last line
     try:
@@ -580,6 +614,7 @@ def main():
     if args.workload == "launch-selftest":
         return run_launch_selftest(args, rank, world)
 
+    blocking_sync(local_rank)
     import torch
     from paintmind_amd import ops
     if rank != 0:
@@ -670,20 +705,40 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     ru0 = resource.getrusage(resource.RUSAGE_SELF)      # process-wide: the main thread, lane threads, the HIP runtime's helpers
+    th0 = thread_cpu_seconds()
     t0 = time.perf_counter()
+    # The host stays at most PACE steps ahead of the GPU: before step i is enqueued it SLEEPS (blocking event) until step
+    # i - PACE has finished.  Unpaced, the launch calls of a long run block on the full hardware queue and that wait spins:
+    # a whole core per rank for nothing (measured at 20 steps: 101 ms of CPU per 133 ms step).  Two steps (0.26 s of queued
+    # GPU work) of slack keep the GPU fed.
+    paced = []
     for i in range(args.steps):
+        if len(paced) >= PACE:
+            for ev in paced.pop(0):
+                ev.synchronize()
         if free_running:
             parts = step(args.warmup + i, join=False)   # lanes keep their own stream order; device-wide sync below joins them
             if dist is not None:
                 gather_lanes(parts)
+            evs = []
+            for _, _, st in parts:
+                ev = torch.cuda.Event(blocking=True)
+                ev.record(st)
+                evs.append(ev)
+            paced.append(evs)
         else:
             gather(step(args.warmup + i))
+            ev = torch.cuda.Event(blocking=True)
+            ev.record()
+            paced.append([ev])
     host_enqueue = time.perf_counter() - t0             # wall time until the last step is enqueued: INCLUDES the time the launch
     ru1 = resource.getrusage(resource.RUSAGE_SELF)      # calls block on a full hardware queue (back-pressure, not host work)
     drain_gathers()
     torch.cuda.synchronize(device)
     own_elapsed = time.perf_counter() - t0              # this rank's own K steps (before waiting for the slowest rank)
     ru2 = resource.getrusage(resource.RUSAGE_SELF)
+    th1 = thread_cpu_seconds()
+    by_thread = sorted(((th1[t][1] - th0.get(t, (None, 0.0))[1], th1[t][0]) for t in th1), reverse=True)
     cpu_enqueue = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
     cpu_total = (ru2.ru_utime + ru2.ru_stime) - (ru0.ru_utime + ru0.ru_stime)   # incl. the closing synchronize (a spin or a sleep)
     if dist is not None:
@@ -725,6 +780,7 @@ def main():
         "host_cpu_ms_per_step_incl_sync": round(cpu_total / args.steps * 1e3, 3),
         "host_cpu_fraction_of_one_core": round(cpu_total / max(own_elapsed, 1e-9), 4),
         "host_enqueue_wall_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
+        "host_cpu_ms_per_step_by_thread": [{"thread": nm, "cpu_ms_per_step": round(sec / args.steps * 1e3, 2)} for sec, nm in by_thread[:4] if sec > 0],
         "per_rank_host_cpu_ms_per_step": [round(c[1] / args.steps * 1e3, 3) for c in per_rank_cpu],
         # the path's only collective: finished images of one step -> rank 0 (0 without a process group)
         "gather_bytes_per_step_per_rank": (B * 3 * 256 * 256 * 4 if cfg0 is None else B * 3 * img_px * img_px * 4) if dist is not None else 0,

@@ -28,6 +28,17 @@
 #define ABL 0                 // ablation bit mask (tools/hwtests/attn_abl.hip); 0 in the library
 #endif
 
+#ifdef PM_ATTN_COUNT
+// DEBUG BUILD ONLY (tools/attn_rescale_count.sh): how often the steady loop leaves its fast path on real data.
+// [0] wave-level executions of the rescale branch inside the steady loop, [1] steady half-tile steps (per wave), [2] slow steps
+__device__ unsigned long long g_attn_counters[4];
+extern "C" int pmhip_debug_attention_counters(unsigned long long* out4, int reset) {
+    if (out4 && hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_attn_counters), 32) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_counters), z, 32) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
 namespace {
 
 constexpr int KT = 64;        // keys per tile
@@ -346,7 +357,12 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
         __builtin_amdgcn_sched_barrier(0);
         DSRX(kf[1][0], ka, 1 * 512 + 1 * 64); DSRX(kf[1][1], ka, 1 * 512 + 0 * 64);
         if constexpr (ABL & 16) asm volatile("" :: "v"(m));
-        else if (__builtin_expect(__any(__int_as_float(m) > kDefer), 0)) rescale(std::false_type{}, std::false_type{}, sn, hh + 1);
+        else if (__builtin_expect(__any(__int_as_float(m) > kDefer), 0)) {
+#ifdef PM_ATTN_COUNT
+            if (lane == 0) atomicAdd(&g_attn_counters[0], 1ull);
+#endif
+            rescale(std::false_type{}, std::false_type{}, sn, hh + 1);
+        }
     };
 
     // The same half-tile with every condition at run time and full waits: first and last tiles, ragged tiles, short contexts.
@@ -400,6 +416,9 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
         step(Y, sA, sB, hs);
         step(N, sB, sA, hs + 1);
     }
+#ifdef PM_ATTN_COUNT
+    if (lane == 0) { atomicAdd(&g_attn_counters[1], (unsigned long long)hs); atomicAdd(&g_attn_counters[2], (unsigned long long)(nhalves - hs)); }
+#endif
     for (; hs < nhalves; ++hs) slow_step(hs);
 
     // ---- finalize: O = O^T / l, head-major inside the output row.  The wave's 64 output rows go through the (now idle)

@@ -217,9 +217,12 @@ struct Switches {
         w.stats = !(e && atoi(e) == 0);
         e = getenv("PMHIP_FOLD_MAX_ROWS");
         w.fold_rows_cap = e ? atoi(e) : 0;
+        e = getenv("PMHIP_BLOCKING_WAIT");
+        w.blocking_wait = e && atoi(e) != 0;
         return w;
     }
     int fold_rows_cap = 0;  // PMHIP_FOLD_MAX_ROWS (development / tests): cap on the rows one folded launch takes, see fold_rows()
+    bool blocking_wait = false;   // PMHIP_BLOCKING_WAIT=1: host waits between decode-loop segments sleep instead of spinning
     int key() const { return (hilo ? 2 : 0) + (fold ? 1 : 0) + (stats ? 4 : 0); }
 };
 
@@ -785,7 +788,10 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
     const bool graph = use_graph && !g_pm_timing_on.load() && T <= PM_MAX_STEPS;
 
     if (imgs_host) {
-        const unsigned evflags = hipEventDisableTiming;
+        // PMHIP_BLOCKING_WAIT=1 (read when the handle is created): the lane's host thread SLEEPS in hipEventSynchronize while its
+        // segment runs instead of spinning -- frees a core per lane on a host that is short of them, at 0.6 ms of wake-up latency
+        // per saved image (measured: the drop-in generate() 151 vs 141 ms per call), hence off by default
+        const unsigned evflags = hipEventDisableTiming | (s2->sw.blocking_wait ? hipEventBlockingSync : 0u);
         if (!s2->host_copied) PM_HIP(hipEventCreateWithFlags(&s2->host_copied, evflags));
         while ((int)s2->img_ready.size() < n_dec) {
             hipEvent_t e;
