@@ -494,7 +494,7 @@ def pmc_traffic(workload, dtype, family):
 CALIBRATION_REFERENCE_TFLOPS = 1500.0     # the 8192^3 rate `frac_calibrated` is normalised to (middle of the pool's 1.40-1.65 PFLOP/s)
 
 
-def gemm_calibration(device, iters=12):
+def gemm_calibration(device, iters=8):
     """this library's 8192 x 8192 x 8192 bf16 GEMM on this box, hipEvent-timed (about 10 ms in total)"""
     import torch
     from paintmind_amd import ops
@@ -503,13 +503,16 @@ def gemm_calibration(device, iters=12):
     w = (torch.rand(8192, 8192, generator=g) * 2 - 1).to(device, torch.bfloat16)
     for _ in range(3):
         ops.gemm(a, w, out_dtype=torch.bfloat16)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops.gemm(a, w, out_dtype=torch.bfloat16)
-    e1.record()
-    torch.cuda.synchronize(device)
-    ms = e0.elapsed_time(e1) / iters
+    best = 1e30
+    for _ in range(3):                                       # best of three batches: the rate drifts with the chip's power state
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.gemm(a, w, out_dtype=torch.bfloat16)
+        e1.record()
+        torch.cuda.synchronize(device)
+        best = min(best, e0.elapsed_time(e1) / iters)
+    ms = best
     return {"gemm_8192_bf16_tflops": round(2 * 8192 ** 3 / (ms * 1e-3) / 1e12, 1), "reference_tflops": CALIBRATION_REFERENCE_TFLOPS,
             "note": "frac_calibrated = frac x reference / measured: comparable across boxes of the pool (spread +-3..8 %)"}
 

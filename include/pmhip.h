@@ -92,6 +92,22 @@ int pmhip_gemm_hilo(const void* A, int lda, const void* W, int ldw, const float*
 int pmhip_gemm_hilo_stats(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
                           const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N,
                           int K, float* row_stats, pmhip_stream stream);
+
+/* Round 4, the CENTRED hi plane.  The folded LayerNorm normalises bf16(x); a row whose common offset is large against its spread
+ * (trained transformers: massive activations, drifting row means) then loses 2^-9 |x| / std per element.  LayerNorm is blind to
+ * a per-row shift, so this producer stores the pair of x - c, c = the row mean of the PREVIOUS hi plane read from `center_coef`
+ * ([M][2] = the (rstd, -rstd * mean) pairs of pmhip_ln_coef / pmhip_ln_coef_parts for the LayerNorm in front of this branch;
+ * NULL = no centring) plus `center_extra`, a launch-wide constant (the mean of `bias` over its N columns: the part of the new row
+ * mean that is known in advance; a sudden common offset is then removed in the producer that introduces it).  `shift` ([M] floats, optional): running sum of the subtracted values for callers that need the absolute
+ * x again (pmhip_unshift_hilo); shift_mode 1 = this producer opens the stream (shift <- 0), 2 = shift += c, 0 = untouched.
+ * Everything else as pmhip_gemm_hilo_stats (row_stats may be NULL).  Replaces the same residual adds:
+ * stage1/layers.py:55-56, stage2/transformer.py:45-48. */
+int pmhip_gemm_hilo_center(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
+                           const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N, int K,
+                           float* row_stats, const float* center_coef, float center_extra, float* shift, int shift_mode,
+                           pmhip_stream stream);
+/* (hi, lo) <- split(hi + lo + shift[row]) in place: a centred stream back to the plain pair (D <= 1024, D % 4 == 0) */
+int pmhip_unshift_hilo(void* x_hi, void* x_lo, const float* shift, int M, int D, pmhip_stream stream);
 /* row operators on the pair (D a multiple of 4, <= 1024): LayerNorm of hi + lo -> f32 / bf16 (the unfolded path);
  * LayerNorm of an f32 row -> hi, lo; f32 -> hi, lo and back */
 int pmhip_layernorm_hilo(const void* x_hi, const void* x_lo, const float* gamma, const float* beta, float eps,
@@ -250,6 +266,9 @@ typedef struct pmhip_layer_weights {
     const void* wqkv_f; const float* qkv_c; const float* qkv_d;        /* norm1 into attn1 q|k|v               */
     const void* wqkv2_f; const float* qkv2_c; const float* qkv2_d;     /* stage 2: norm2 into attn2 q|k|v      */
     const void* w12p_f; const float* w12_c; const float* w12_d;        /* the FFN norm into packed w12         */
+    /* centred hi plane (pmhip_gemm_hilo_center): mean over the columns of the three residual-producer biases -- what a producer
+     * adds to EVERY row's mean, known before the row is computed (0 when unused)                                          */
+    float bo_mean, bo2_mean, b3_mean;
 } pmhip_layer_weights;
 
 typedef struct pmhip_tower_cfg {

@@ -27,7 +27,8 @@ class LayerWeights(C.Structure):
     _fields_ = [(n, vp) for n in (
         "ln1_g", "ln1_b", "wqkv", "wo", "bo", "lnx_g", "lnx_b", "wqkv2", "wo2", "bo2",
         "ln2_g", "ln2_b", "w12p", "b12p", "w3p", "b3",
-        "wqkv_f", "qkv_c", "qkv_d", "wqkv2_f", "qkv2_c", "qkv2_d", "w12p_f", "w12_c", "w12_d")]
+        "wqkv_f", "qkv_c", "qkv_d", "wqkv2_f", "qkv2_c", "qkv2_d", "w12p_f", "w12_c", "w12_d")] + \
+        [("bo_mean", C.c_float), ("bo2_mean", C.c_float), ("b3_mean", C.c_float)]
 
 
 class TowerCfg(C.Structure):
@@ -74,6 +75,8 @@ PROTOTYPES = {
                                C.POINTER(vp), f32, vp]),
     "pmhip_gemm_hilo": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp]),
     "pmhip_gemm_hilo_stats": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "pmhip_gemm_hilo_center": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, C.c_float, vp, i32, vp]),
+    "pmhip_unshift_hilo": (i32, [vp, vp, vp, i32, i32, vp]),
     "pmhip_ln_coef_parts": (i32, [vp, i32, f32, vp, i32, vp]),
     "pmhip_layernorm_hilo": (i32, [vp, vp, vp, vp, f32, vp, i32, i32, i32, vp]),
     "pmhip_layernorm_to_hilo": (i32, [vp, vp, vp, f32, vp, vp, i32, i32, vp]),

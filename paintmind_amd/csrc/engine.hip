@@ -170,6 +170,10 @@ struct TowerBufs {
     float* coef = nullptr;  // LayerNorm fold: per-row (rstd, -rstd * mean) of the hi plane
     float* parts = nullptr; // ... and the partial row statistics the last residual GEMM left behind, [M, dim/64, 2]
     bool parts_valid = false;   // parts describe the CURRENT hi plane (set by residual_gemm, see tower_coef)
+    // centred hi plane (gemm_common.h, GemmParams::center_coef): the producers subtract the row mean the last LayerNorm saw
+    bool center = false;        // mode on (fold on and not PMHIP_HILO_CENTER=0)
+    bool coef_valid = false;    // coef holds the statistics of the CURRENT hi plane (set by tower_coef, cleared by a producer)
+    float* shift = nullptr;     // per-row running sum of the subtracted means: only where the absolute x is needed again (ViT encoder)
     bool hilo = false;      // bf16 mode
     int fold_rows_cap = 0;  // Switches::fold_rows_cap
     bool stats = true;      // producers leave row statistics (PMHIP_LN_STATS=0: the coefficient pass over the plane, A/B tests)
@@ -217,13 +221,16 @@ struct Switches {
         w.stats = !(e && atoi(e) == 0);
         e = getenv("PMHIP_FOLD_MAX_ROWS");
         w.fold_rows_cap = e ? atoi(e) : 0;
+        e = getenv("PMHIP_HILO_CENTER");
+        w.center = !(e && atoi(e) == 0);
         e = getenv("PMHIP_BLOCKING_WAIT");
         w.blocking_wait = e && atoi(e) != 0;
         return w;
     }
     int fold_rows_cap = 0;  // PMHIP_FOLD_MAX_ROWS (development / tests): cap on the rows one folded launch takes, see fold_rows()
+    bool center = true;     // PMHIP_HILO_CENTER=0: the residual producers do not centre the hi plane (A/B, tests)
     bool blocking_wait = false;   // PMHIP_BLOCKING_WAIT=1: host waits between decode-loop segments sleep instead of spinning
-    int key() const { return (hilo ? 2 : 0) + (fold ? 1 : 0) + (stats ? 4 : 0); }
+    int key() const { return (hilo ? 2 : 0) + (fold ? 1 : 0) + (stats ? 4 : 0) + (center ? 8 : 0); }
 };
 
 // widest residual stream the hi/lo row operators (pmhip_split_hilo, pmhip_layernorm_hilo, pmhip_layernorm_to_hilo, pmhip_ln_coef,
@@ -257,6 +264,9 @@ int alloc_tower(Workspace& ws, const Switches& sw, const char* tag, int dtype, c
     b.fold = b.hilo && dh == 64 && sw.fold;
     b.stats = sw.stats;
     b.fold_rows_cap = sw.fold_rows_cap;
+    b.center = b.fold && sw.center;
+    b.coef_valid = false;
+    b.shift = nullptr;
     return PMHIP_OK;
 }
 
@@ -269,12 +279,19 @@ ResSrc res_self(const TowerBufs& b, int dim) {
 
 // residual GEMM x = A . W^T + bias + addend, written to the tower's residual stream (in place when the addend is the stream)
 int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W, int ldw, const float* bias, const ResSrc& r,
-                  int M, int N, int K, hipStream_t s) {
+                  int M, int N, int K, hipStream_t s, float bias_mean = 0.f) {
     if (b.hilo) {
         // with the LayerNorm folded into the consumers the producer's epilogue also leaves the row statistics of the new hi plane
         // (16 bytes per 64 columns): the coefficient pass over the plane (pmhip_ln_coef, 14 us per launch at the bench shape)
         // becomes a combination of 8-16 partials per row.  PMHIP_LN_STATS=0: the pass (A/B).
         b.parts_valid = b.fold && N % 64 == 0 && N <= 1024 && b.stats;   // pmhip_ln_coef_parts combines <= 16 parts
+        const bool self = r.hi == b.xh && r.rows == 0;                 // x += ... (not the GEMM that opens the stream)
+        const float* cc = (b.center && self && b.coef_valid) ? b.coef : nullptr;
+        const int shift_mode = !b.shift ? 0 : (self ? (cc ? 2 : 0) : 1);
+        b.coef_valid = false;                                          // the hi plane changes
+        if (cc || b.shift)
+            return pmhip_gemm_hilo_center(A, lda, W, ldw, bias, r.hi, r.lo, r.ld, r.rows, b.xh, b.xl, N, M, N, K, b.parts_valid ? b.parts : nullptr,
+                                          cc, bias_mean, b.shift, shift_mode, s);
         if (b.parts_valid) return pmhip_gemm_hilo_stats(A, lda, W, ldw, bias, r.hi, r.lo, r.ld, r.rows, b.xh, b.xl, N, M, N, K, b.parts, s);
         return pmhip_gemm_hilo(A, lda, W, ldw, bias, r.hi, r.lo, r.ld, r.rows, b.xh, b.xl, N, M, N, K, s);
     }
@@ -283,6 +300,7 @@ int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W
 
 // (rstd, -rstd * mean) of the rows of the current hi plane into b.coef
 int tower_coef(TowerBufs& b, int M, int dim, hipStream_t s) {
+    b.coef_valid = true;
     if (b.parts_valid) return pmhip_ln_coef_parts(b.parts, dim / 64, 1e-5f, b.coef, M, s);
     return pmhip_ln_coef(b.xh, 1e-5f, b.coef, M, dim, s);
 }
@@ -353,7 +371,7 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
                         q_scale, s));
     }
     PM_TRY(pmhip_attention_dh(dtype, b.q, b.k, b.vt, b.attn, inner, B, tc.heads, dh, tokens, tokens, Np, fast, s));
-    PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo, inner, L.bo, self, M, dim, inner, s));
+    PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo, inner, L.bo, self, M, dim, inner, s, L.bo_mean));
 
     if (stage2) {
         // x = attn2(norm2(x), context) + x ; context None -> a second self-attention (attention.py:47)
@@ -369,7 +387,7 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
                             outs, q_scale, s));
             PM_TRY(pmhip_attention_dh(dtype, b.q, b.k, b.vt, b.attn, inner, B, tc.heads, dh, tokens, tokens, Np, fast, s));
         }
-        PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo2, inner, L.bo2, self, M, dim, inner, s));
+        PM_TRY(residual_gemm(dtype, b, b.attn, inner, L.wo2, inner, L.bo2, self, M, dim, inner, s, L.bo2_mean));
     }
 
     // x = ffnet(norm(x)) + x
@@ -386,7 +404,7 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
         PM_TRY(tower_layernorm(dtype, b, L.ln2_g, L.ln2_b, M, dim, s));
         PM_TRY(pmhip_gemm_swiglu(dtype, b.y, dim, L.w12p, L.b12p, b.hid, tc.hidden_pad, M, tc.hidden_pad, dim, s));
     }
-    return residual_gemm(dtype, b, b.hid, tc.hidden_pad, L.w3p, tc.hidden_pad, L.b3, self, M, dim, tc.hidden_pad, s);
+    return residual_gemm(dtype, b, b.hid, tc.hidden_pad, L.w3p, tc.hidden_pad, L.b3, self, M, dim, tc.hidden_pad, s, L.b3_mean);
 }
 
 // a position embedding as the addend of the GEMM that opens a residual stream: the fp32 table in verify mode, its hi / lo
@@ -472,8 +490,15 @@ int vq_encoder(pmhip_vqgan* h, const float* img, int B, TowerBufs& tb, hipStream
                       PMHIP_F32, M, dim, h->patch_k, s));
     if (tb.hilo) PM_TRY(pmhip_layernorm_to_hilo(x0, h->w.pre_g, h->w.pre_b, 1e-5f, tb.xh, tb.xl, M, dim, s));
     else PM_TRY(pmhip_layernorm(x0, h->w.pre_g, h->w.pre_b, 1e-5f, tb.x, PMHIP_F32, M, dim, s));
+    if (tb.center) {
+        // prev_quant (vqmodel.py:23) consumes the ABSOLUTE residual stream, so this tower keeps the running shift of its centred
+        // hi plane and folds it back in at the end (the decoder and the stage-2 tower end in a LayerNorm, which never sees it)
+        WS(h->ws, "enc.shift", (size_t)M * 4, tb.shift);
+        PM_HIP(hipMemsetAsync(tb.shift, 0, (size_t)M * 4, s));
+    }
     for (int l = 0; l < c.enc.depth; ++l)
         PM_TRY(layer_forward(h->dtype, h->enc_layers[l], c.enc, tb, B, h->tokens, false, nullptr, s));
+    if (tb.shift) PM_TRY(pmhip_unshift_hilo(tb.xh, tb.xl, tb.shift, M, dim, s));
     return PMHIP_OK;
 }
 
@@ -875,7 +900,7 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
 
     std::string key = "B" + std::to_string(B) + "T" + std::to_string(T) + "k" + std::to_string(topk) + "L" +
                       std::to_string(context ? L : 0) + "v" + std::to_string(vq ? vq->uid : 0) + "f" +
-                      std::to_string(s2->sw.key() * 8 + (vq ? vq->sw.key() : 0)) + "d";
+                      std::to_string(s2->sw.key() * 16 + (vq ? vq->sw.key() : 0)) + "d";
     for (int t = 0; t < T; ++t) key += (decode_host && decode_host[t]) ? '1' : '0';
     GraphEntry& ge = s2->graphs[key];
 

@@ -229,8 +229,13 @@ extern "C" int pmhip_gemm(int dtype, const void* A, int lda, const void* W, int 
 // row_stats (optional): per-row partial statistics of the new hi plane, [M][N/64][2] (gemm_common.h)
 static int gemm_hilo_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
                           const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N, int K,
-                          float* row_stats, pmhip_stream stream) {
+                          float* row_stats, pmhip_stream stream, const float* center_coef = nullptr, float center_extra = 0.f,
+                          float* shift = nullptr, int shift_mode = 0) {
     GemmParams p{};
+    p.center_coef = center_coef; p.center_extra = center_coef ? center_extra : 0.f; p.shift = shift; p.shift_mode = shift ? shift_mode : 0;
+    PM_REQUIRE(shift_mode >= 0 && shift_mode <= 2, "gemm_hilo_center: shift_mode=%d", shift_mode);
+    PM_REQUIRE(!(center_coef || shift_mode == 2) || res_rows <= 0 || res_rows >= M,
+               "gemm_hilo_center: centring / shift accumulation needs the residual to be the stream itself (no row modulo)");
     p.A = A; p.W = W; p.bias = bias; p.residual = reinterpret_cast<const float*>(res_hi); p.out = out_hi;
     p.res_lo = reinterpret_cast<const bf16_t*>(res_lo); p.out_lo = reinterpret_cast<bf16_t*>(out_lo);
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.res_rows = res_rows > 0 ? res_rows : M; p.ldo = ldo;
@@ -257,6 +262,15 @@ extern "C" int pmhip_gemm_hilo_stats(const void* A, int lda, const void* W, int 
                                      int K, float* row_stats, pmhip_stream stream) {
     PM_REQUIRE(row_stats, "gemm_hilo_stats: null statistics buffer");
     return gemm_hilo_impl(A, lda, W, ldw, bias, res_hi, res_lo, ldr, res_rows, out_hi, out_lo, ldo, M, N, K, row_stats, stream);
+}
+
+// the same producer storing the pair of x - (row mean of the previous hi plane): gemm_common.h, GemmParams::center_coef
+extern "C" int pmhip_gemm_hilo_center(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res_hi,
+                                      const void* res_lo, int ldr, int res_rows, void* out_hi, void* out_lo, int ldo, int M, int N,
+                                      int K, float* row_stats, const float* center_coef, float center_extra, float* shift,
+                                      int shift_mode, pmhip_stream stream) {
+    return gemm_hilo_impl(A, lda, W, ldw, bias, res_hi, res_lo, ldr, res_rows, out_hi, out_lo, ldo, M, N, K, row_stats, stream, center_coef,
+                          center_extra, shift, shift_mode);
 }
 
 extern "C" int pmhip_gemm_ln(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldo,

@@ -311,7 +311,9 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
             if (p.residual) wave_epilogue<EPI, OutT, 8, 1, true, 1>(p, acc, eraw, mw, nw, lane, no_pre);
             else wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, mw, nw, lane, no_pre);
         } else if constexpr (EPI == EPI_STD) {
-            if (p.out_lo) wave_epilogue<EPI, OutT, 8, 1, true, 2>(p, acc, eraw, mw, nw, lane, no_pre);      // bf16 hi/lo residual stream
+            // bf16 hi/lo residual stream: a producer never has a LayerNorm folded in (launch256 checks), so the folded kernel does
+            // not carry that epilogue
+            if (!FOLD && p.out_lo) wave_epilogue<EPI, OutT, 8, 1, true, 2>(p, acc, eraw, mw, nw, lane, no_pre);
             else wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, mw, nw, lane, no_pre);
         } else {
             wave_epilogue<EPI, OutT, 8, 1, true, 0>(p, acc, eraw, mw, nw, lane, no_pre);
@@ -338,6 +340,7 @@ int launch256(const GemmParams& p0, hipStream_t s) {
     static int persist = -1;                     // PMHIP_PERSIST256: workgroups of the persistent grid (0 = one per tile)
     if (persist < 0) { const char* e = getenv("PMHIP_PERSIST256"); persist = e ? atoi(e) : 256; }
     const int grid = (persist > 0 && tiles > persist) ? persist : tiles;
+    if (p.ln_coef && p.out_lo) { pm_set_error("gemm256: a hi/lo residual producer cannot have a LayerNorm folded in"); return PMHIP_EINVAL; }
     PmTimer tm(gemm_family(p, EPI), s);
     if (p.ln_coef) hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, true>), dim3(grid), dim3(THREADS), 0, s, p);
     else hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, false>), dim3(grid), dim3(THREADS), 0, s, p);

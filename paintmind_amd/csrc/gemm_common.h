@@ -34,6 +34,16 @@ struct GemmParams {
     // row_stats[m][N/64][2] = (sum, centred sum of squares) of the 64 columns a wave owns; pmhip_ln_coef_parts combines them
     // (Chan's update, fixed order).  Needs N % 64 == 0.
     float* row_stats;
+    // CENTRED hi plane (round 4).  The folded LayerNorm normalises bf16(x): a row whose common offset is large against its spread
+    // loses 2^-9 |x| / std per element (tests/test_gpu_ops.py::test_layernorm_fold_accuracy_...: 7x the unfolded kernel's error
+    // at offset 50 std).  LayerNorm does not see a per-row shift, so the producer stores the pair of x - c with c = the row mean
+    // of the PREVIOUS hi plane, taken from the (rstd, -rstd * mean) pair the LayerNorm in front of this branch left in
+    // `center_coef` ([M][2], pmhip_ln_coef / pmhip_ln_coef_parts): the new hi plane is centred up to the branch's own mean and
+    // rounds like LN(x) does.  `shift` ([M], optional): running sum of the subtracted values, kept only where the absolute x is
+    // needed again (the ViT encoder's prev_quant); shift_mode 1 = this producer opens the stream (shift <- 0), 2 = shift += c.
+    // center_extra: a launch-wide constant added to c -- the mean of this producer's bias over its columns, the part of the new
+    // row mean that is known before the row is computed.
+    const float* center_coef; float center_extra; float* shift; int shift_mode;
     // LayerNorm fold, consumer side (256x256 kernel): A is the RAW bf16 row (the hi plane), W carries gamma, and the epilogue
     // applies out = rstd * acc - rstd * mean * c[n] + d[n]
     const float* ln_coef;                          // [M][2]: (rstd, -rstd * mean) per row, from pmhip_ln_coef
@@ -379,10 +389,15 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
 #endif
     constexpr int HD = PIPE_HILO ? (PM_HILO_DEPTH < MI ? PM_HILO_DEPTH : MI) : 1;
     [[maybe_unused]] uint4 hq[HD][ITERS] = {}, lq[HD][ITERS] = {};
+    [[maybe_unused]] float2 cq[HD][ITERS] = {};                 // (rstd, -rstd * mean) of the previous hi plane, per row of the slice
+    [[maybe_unused]] float sq[HD][ITERS] = {};                  // running shift of the row (only the wave of column block 0 keeps it)
+    [[maybe_unused]] const bool keeps_shift = HILO && p.shift && p.shift_mode == 2 && nw == 0;
     [[maybe_unused]] const bf16_t* res_hi = reinterpret_cast<const bf16_t*>(p.residual);
-    [[maybe_unused]] auto load_pair = [&](int slice, uint4 (&h)[ITERS], uint4 (&l)[ITERS]) {
+    [[maybe_unused]] auto load_pair = [&](int slice, uint4 (&h)[ITERS], uint4 (&l)[ITERS], float2 (&c)[ITERS], float (&sh)[ITERS]) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
+            if (p.center_coef) c[it] = *reinterpret_cast<const float2*>(p.center_coef + (size_t)(mwave + slice * 16 + it * RPI + lane / LPR) * 2);
+            if (keeps_shift) sh[it] = p.shift[mwave + slice * 16 + it * RPI + lane / LPR];
 #ifdef PM_ABL_NO_RESLOAD
             h[it] = make_uint4(0x3f803f80u + slice, 0, 0, 0); l[it] = make_uint4(0, 0, 0, 0);
 #else
@@ -394,7 +409,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
     };
     if constexpr (PIPE_HILO) {
 #pragma unroll
-        for (int d = 0; d < HD; ++d) load_pair(d, hq[d], lq[d]);
+        for (int d = 0; d < HD; ++d) load_pair(d, hq[d], lq[d], cq[d], sq[d]);
     }
     constexpr bool PIPE_RES = (EPI == EPI_STD) && FULL && RES == 1 && NPRE == 1 && sizeof(OutT) == 4;
     float4 rnext[ITERS] = {};
@@ -417,10 +432,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             }
         }
         [[maybe_unused]] uint4 hcur[ITERS], lcur[ITERS];
+        [[maybe_unused]] float2 ccur[ITERS] = {};
+        [[maybe_unused]] float scur[ITERS] = {};
         if constexpr (PIPE_HILO) {                          // ring slot mi % HD (mi is a compile-time constant after unrolling)
 #pragma unroll
-            for (int it = 0; it < ITERS; ++it) { hcur[it] = hq[mi % HD][it]; lcur[it] = lq[mi % HD][it]; }
-            if (mi + HD < MI) load_pair(mi + HD, hq[mi % HD], lq[mi % HD]);
+            for (int it = 0; it < ITERS; ++it) { hcur[it] = hq[mi % HD][it]; lcur[it] = lq[mi % HD][it]; ccur[it] = cq[mi % HD][it]; scur[it] = sq[mi % HD][it]; }
+            if (mi + HD < MI) load_pair(mi + HD, hq[mi % HD], lq[mi % HD], cq[mi % HD], sq[mi % HD]);
         }
         const int mbase = mwave + mi * 16;
         if constexpr (GATE_IN_REGS) {
@@ -492,18 +509,28 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                     }
                     if constexpr (HILO) {
                         uint4 rh, rl;
-                        if constexpr (PIPE_HILO) { rh = hcur[it]; rl = lcur[it]; }
+                        float2 cc = make_float2(1.f, 0.f);
+                        float sh = 0.f;
+                        if constexpr (PIPE_HILO) { rh = hcur[it]; rl = lcur[it]; cc = ccur[it]; sh = scur[it]; }
                         else {
                             const size_t off = (size_t)(mm % p.res_rows) * p.ldr + ncol;
                             rh = *reinterpret_cast<const uint4*>(res_hi + off);
                             rl = *reinterpret_cast<const uint4*>(p.res_lo + off);
+                            if (p.center_coef) cc = *reinterpret_cast<const float2*>(p.center_coef + (size_t)mm * 2);
+                            if (keeps_shift) sh = p.shift[mm];
+                        }
+                        // the row mean of the previous hi plane (0 without centring); every wave of the row derives the same bits
+                        const float cen = p.center_coef ? p.center_extra - cc.y * __builtin_amdgcn_rcpf(cc.x) : 0.f;
+                        if (p.shift && nw == 0 && (lane & (LPR - 1)) == 0) {
+                            if (p.shift_mode == 1) p.shift[mm] = 0.f;
+                            else if (p.shift_mode == 2) p.shift[mm] = sh + cen;
                         }
                         const unsigned hw[4] = {rh.x, rh.y, rh.z, rh.w}, lw[4] = {rl.x, rl.y, rl.z, rl.w};
                         unsigned oh[4], ol[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {              // two columns per word; hi + lo is exact in f32
-                            const float x0 = v[2 * j] + (__uint_as_float(hw[j] << 16) + __uint_as_float(lw[j] << 16));
-                            const float x1 = v[2 * j + 1] + (__uint_as_float(hw[j] & 0xffff0000u) + __uint_as_float(lw[j] & 0xffff0000u));
+                            const float x0 = v[2 * j] + ((__uint_as_float(hw[j] << 16) + __uint_as_float(lw[j] << 16)) - cen);
+                            const float x1 = v[2 * j + 1] + ((__uint_as_float(hw[j] & 0xffff0000u) + __uint_as_float(lw[j] & 0xffff0000u)) - cen);
                             oh[j] = pack_bf16x2(x0, x1);
                             ol[j] = pack_bf16x2(x0 - __uint_as_float(oh[j] << 16), x1 - __uint_as_float(oh[j] & 0xffff0000u));
                         }

@@ -230,12 +230,13 @@ template <bool IN_HILO, int MODE>
 __global__ __launch_bounds__(THREADS) void hilo_rows_kernel(const float* __restrict__ x, const bf16_t* __restrict__ xh,
                                                             const bf16_t* __restrict__ xl, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, void* __restrict__ out,
-                                                            bf16_t* __restrict__ out_lo, int M, int D) {
+                                                            bf16_t* __restrict__ out_lo, int M, int D, const float* __restrict__ shift) {
     constexpr int MAXV = 4;                                      // 4 columns per lane per step, D <= 1024
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
     if (row >= M) return;
     const size_t base = (size_t)row * D;
+    const float sh = (IN_HILO && shift) ? shift[row] : 0.f;     // centred stream (gemm_common.h): x = hi + lo + shift[row]
     const int nv = (D + 255) / 256;
     float4 v[MAXV];
     float s = 0.f;
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(THREADS) void hilo_rows_kernel(const float* __restr
                 v[i].y = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
                 v[i].z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
                 v[i].w = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+                if (shift) { v[i].x += sh; v[i].y += sh; v[i].z += sh; v[i].w += sh; }
             } else {
                 v[i] = *reinterpret_cast<const float4*>(x + base + c0);
             }
@@ -373,12 +375,12 @@ __global__ __launch_bounds__(THREADS) void ln_coef_parts_kernel(const float2* __
 
 template <bool IN_HILO, int MODE>
 static int launch_hilo(const float* x, const void* xh, const void* xl, const float* g, const float* b, float eps, void* out, void* out_lo,
-                       int M, int D, hipStream_t s) {
+                       int M, int D, hipStream_t s, const float* shift = nullptr) {
     PM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "hi/lo row operator: D=%d must be a multiple of 4, <= 1024", D);
     PmTimer tm(FAM_LAYERNORM, s);
     hipLaunchKernelGGL((hilo_rows_kernel<IN_HILO, MODE>), dim3(ceil_div(M, THREADS / 64)), dim3(THREADS), 0, s, x,
                        reinterpret_cast<const bf16_t*>(xh), reinterpret_cast<const bf16_t*>(xl), g, b, eps, out,
-                       reinterpret_cast<bf16_t*>(out_lo), M, D);
+                       reinterpret_cast<bf16_t*>(out_lo), M, D, shift);
     PM_HIP(hipGetLastError());
     return PMHIP_OK;
 }
@@ -409,6 +411,12 @@ extern "C" int pmhip_split_hilo(const float* x, void* out_hi, void* out_lo, int 
 extern "C" int pmhip_join_hilo(const void* x_hi, const void* x_lo, float* out, int M, int D, pmhip_stream stream) {
     PM_REQUIRE(x_hi && x_lo && out, "join_hilo: null pointer");
     return launch_hilo<true, HL_JOIN>(nullptr, x_hi, x_lo, nullptr, nullptr, 0.f, out, nullptr, M, D, (hipStream_t)stream);
+}
+
+// centred stream -> plain pair, in place: (hi, lo) <- split(hi + lo + shift[row]) (where the absolute x is needed again)
+extern "C" int pmhip_unshift_hilo(void* x_hi, void* x_lo, const float* shift, int M, int D, pmhip_stream stream) {
+    PM_REQUIRE(x_hi && x_lo && shift, "unshift_hilo: null pointer");
+    return launch_hilo<true, HL_SPLIT>(nullptr, x_hi, x_lo, nullptr, nullptr, 0.f, x_hi, x_lo, M, D, (hipStream_t)stream, shift);
 }
 
 // per-row (rstd, -rstd * mean) of the hi plane: the coefficients of a GEMM with the LayerNorm folded in (pmhip_lnfold)

@@ -47,6 +47,11 @@ def _pack_layer(layer, dtype, keep, stage2):
     w12p, b12p, hp = packing.pack_w12(layer.ffnet.w12, dtype)
     lw.w12p, lw.b12p = keep(w12p), keep(b12p)
     lw.w3p, lw.b3 = keep(packing.pack_w3(layer.ffnet.w3, hp, dtype)), keep(_f32(layer.ffnet.w3.bias))
+    # what each residual producer adds to every row's mean (centred hi plane, include/pmhip.h)
+    lw.bo_mean = float(a1.to_out[0].bias.detach().float().mean())
+    lw.b3_mean = float(layer.ffnet.w3.bias.detach().float().mean())
+    if stage2:
+        lw.bo2_mean = float(layer.attn2.to_out[0].bias.detach().float().mean())
     if dtype == torch.bfloat16:
         # LayerNorm fold (include/pmhip.h, pmhip_lnfold): gamma-scaled copies of the weights that consume a LayerNorm
         def fold(w32, norm):

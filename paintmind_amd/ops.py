@@ -157,6 +157,32 @@ def gemm_hilo(a, w, res_hi, res_lo, bias=None, res_rows=0, stats=False):
     return hi, lo
 
 
+def gemm_hilo_center(a, w, res_hi, res_lo, bias=None, center_coef=None, shift=None, shift_mode=0, stats=False, center_extra=0.0):
+    """gemm_hilo storing the pair of x - c, c = the row mean of the previous hi plane taken from `center_coef` ([M,2], ln_coef /
+    ln_coef_parts); `shift` [M] fp32 is updated IN PLACE (shift_mode 1: <- 0, 2: += c).  -> (hi, lo[, parts])"""
+    dev = _dev(a, w, res_hi, res_lo, center_coef, shift)
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    hi = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    lo = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    parts = torch.full((M, N // 64, 2), float("nan"), device=dev, dtype=torch.float32) if stats else None
+    with torch.cuda.device(dev):
+        check(lib.pmhip_gemm_hilo_center(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(res_hi), _p(res_lo), res_hi.stride(0), 0,
+                                         _p(hi), _p(lo), N, M, N, K, _p(parts), _p(center_coef), float(center_extra), _p(shift), int(shift_mode),
+                                         stream_ptr(dev)), "pmhip_gemm_hilo_center")
+    return (hi, lo, parts) if stats else (hi, lo)
+
+
+def unshift_hilo(hi, lo, shift):
+    """in place: (hi, lo) <- split(hi + lo + shift[row])"""
+    dev = _dev(hi, lo, shift)
+    M, D = hi.shape
+    with torch.cuda.device(dev):
+        check(_lib.load().pmhip_unshift_hilo(_p(hi), _p(lo), _p(shift), M, D, stream_ptr(dev)), "pmhip_unshift_hilo")
+    return hi, lo
+
+
 def ln_coef_parts(parts, eps=1e-5):
     """per-row (rstd, -rstd * mean) from gemm_hilo(..., stats=True)'s partial statistics -> f32 [M,2]"""
     dev = _dev(parts)

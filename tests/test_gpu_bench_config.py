@@ -297,3 +297,38 @@ def test_bf16_tower_wider_than_the_hilo_row_operators():
     err = (l16 - l32).abs()
     print(f"dim 1280 bf16 vs fp32 logits: max {float(err.max()):.5f} mean {float(err.mean()):.6f} (logits std {float(l32.std()):.3f})")
     assert float(err.max()) < 0.05 and float(err.mean()) < 0.006
+
+
+def test_centred_hi_plane_keeps_the_fold_accurate_on_offset_rows(monkeypatch):
+    """Trained transformers carry residual rows whose common offset dwarfs their spread (massive activations); the folded
+    LayerNorm rounds x to bf16 BEFORE the mean is subtracted and would lose 2^-9 |x| / std there.  Emulated on the 12L/d512
+    transformer by a bias of +30 in the first out-projection (every later LayerNorm then sees rows of offset ~30, spread ~1).
+    With the residual producers centring the hi plane (default) the bf16 logits stay as close to fp32-verify as on the
+    unmodified model; with PMHIP_HILO_CENTER=0 they are several times worse.  LayerNorm is shift-invariant, so fp32-verify itself
+    does not care."""
+    torch.manual_seed(0)
+    pipe = Pipeline(pm.Config(ver2cfg["bench-uncond-12L-d512"]), stage1_pretrained=False).to(dev()).eval()
+    with torch.no_grad():
+        pipe.transformer.layers.layer0.attn1.to_out[0].bias += 30.0
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(0, 8192, (4, 1024), generator=g)
+    ids[torch.rand(4, 1024, generator=g) < 0.5] = pipe.mask_token_id
+    tok = pipe.ids2tokens(ids.to(dev()))
+    l32 = pipe.tokens2logits(tok, None)
+    pipe.set_compute_dtype(torch.bfloat16)
+    err = {}
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("PMHIP_HILO_CENTER", mode)
+            pipe.invalidate_engines()
+            l16 = pipe.tokens2logits(tok, None)
+            assert torch.equal(l16[:1], pipe.tokens2logits(tok[:1], None))                   # batch-invariant either way
+            e = (l16 - l32).abs()
+            err[mode] = (float(e.max()), float(e.mean()), float((l16.argmax(-1) == l32.argmax(-1)).float().mean()))
+    finally:
+        monkeypatch.delenv("PMHIP_HILO_CENTER", raising=False)
+        pipe.invalidate_engines()
+        pipe.set_compute_dtype(torch.float32)
+    print(f"rows of offset 30: bf16 vs fp32 logits (max err, mean err, top-1 agreement): centred {err['1']}, not centred {err['0']}")
+    assert err["1"][0] < BF16_LOGIT_MAXERR * 2 and err["1"][1] < BF16_LOGIT_MEANERR * 2
+    assert err["1"][1] < 0.6 * err["0"][1]

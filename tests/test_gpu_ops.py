@@ -216,6 +216,59 @@ def test_layernorm_fold_consumers():
     assert rel_err(hid[:, :1368], ref) < 3e-2 and rel_err(hid2[:, :1368], ref) < 3e-2 and np.all(hid[:, 1368:] == 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 512),       # two-workgroup kernel
+                                   (8192, 512, 1408),      # 256x256 kernel
+                                   (300, 128, 64)])        # 128x128 kernel, ragged M (unpipelined epilogue)
+def test_gemm_hilo_center(M, N, K):
+    """pmhip_gemm_hilo_center: the producer stores the pair of x - c, c = the row mean of the PREVIOUS hi plane (from the
+    (rstd, -rstd * mean) pairs of pmhip_ln_coef), and accumulates c into `shift`.  hi + lo + shift reproduces the float64 result
+    like the plain producer does; the new hi plane is centred (the rows carry a common offset of 30); its statistics describe
+    the centred plane; pmhip_unshift_hilo folds the shift back in; shift_mode 1 opens a stream (shift <- 0)."""
+    bf = torch.bfloat16
+    a, w, b0 = bf16_round(rnd(M, K, scale=0.7)), bf16_round(rnd(N, K, scale=K ** -0.5)), rnd(N)
+    res = rnd(M, N) * 1.5 + 30.0 + 3.0 * rnd(M, 1)
+    rh, rl = ops.split_hilo(t(res))
+    r64 = n(ops.join_hilo(rh, rl)).astype(np.float64)
+    want = a.astype(np.float64) @ w.astype(np.float64).T + b0 + r64
+    coef = ops.ln_coef(rh) if N % 8 == 0 else None
+    cen = -n(coef)[:, 1].astype(np.float64) / n(coef)[:, 0].astype(np.float64)
+    assert np.abs(cen - n(rh.float()).astype(np.float64).mean(1)).max() < 1e-3
+    shift = torch.full((M,), 7.0, device=dev())
+    stats = N % 64 == 0
+    out = ops.gemm_hilo_center(t(a, bf), t(w, bf), rh, rl, bias=t(b0), center_coef=coef, shift=shift, shift_mode=2, stats=stats)
+    hi, lo = out[0], out[1]
+    sh = n(shift).astype(np.float64)
+    assert np.abs(sh - 7.0 - cen).max() < 1e-4                                    # shift += c
+    got = n(ops.join_hilo(hi, lo)).astype(np.float64) + sh[:, None] - 7.0
+    assert np.max(np.abs(got - want)) < 3e-5 * max(1.0, np.abs(want - cen[:, None]).max()), np.max(np.abs(got - want))
+    assert np.abs(n(hi.float()).mean(1)).max() < 2.0 and np.abs(want.mean(1)).min() > 15.0     # centred plane, offset rows
+    assert bool((lo.float().abs() <= hi.float().abs() * 2.0 ** -8 + 1e-30).all())
+    if stats:
+        h64 = hi.double().cpu().numpy().reshape(M, N // 64, 64)
+        p = out[2].cpu().numpy()
+        assert np.abs(p[..., 0] - h64.sum(-1)).max() < 2e-4
+        assert np.abs(p[..., 1] - ((h64 - h64.mean(-1, keepdims=True)) ** 2).sum(-1)).max() < 2e-3
+    # back to the plain pair
+    sh_t = shift - 7.0
+    uh, ul = ops.unshift_hilo(hi.clone(), lo.clone(), sh_t)
+    back = n(ops.join_hilo(uh, ul)).astype(np.float64)
+    assert np.max(np.abs(back - want) / np.abs(want).max()) < 2.0 ** -15
+    assert bool((ul.float().abs() <= uh.float().abs() * 2.0 ** -8 + 1e-30).all())  # a plain pair again: lo is the remainder of hi
+    # no centring + shift_mode 1: the plain producer's planes bit for bit, shift zeroed
+    hi0, lo0 = ops.gemm_hilo(t(a, bf), t(w, bf), rh, rl, bias=t(b0))
+    hi1, lo1 = ops.gemm_hilo_center(t(a, bf), t(w, bf), rh, rl, bias=t(b0), shift=shift, shift_mode=1)
+    assert torch.equal(hi0, hi1) and torch.equal(lo0, lo1) and float(shift.abs().max()) == 0.0
+    again = ops.gemm_hilo_center(t(a, bf), t(w, bf), rh, rl, bias=t(b0), center_coef=coef)
+    assert torch.equal(again[0], hi) and torch.equal(again[1], lo)               # deterministic; shift optional
+    # center_extra (the mean of the bias: the part of the new row mean known in advance) is subtracted and accounted too
+    shift.fill_(0.0)
+    hx, lx = ops.gemm_hilo_center(t(a, bf), t(w, bf), rh, rl, bias=t(b0 + 20.0), center_coef=coef, shift=shift, shift_mode=2,
+                                  center_extra=float(np.float32(b0.mean() + 20.0)))
+    gotx = n(ops.join_hilo(hx, lx)).astype(np.float64) + n(shift).astype(np.float64)[:, None]
+    assert np.max(np.abs(gotx - (want + 20.0))) < 3e-5 * max(1.0, np.abs(want - cen[:, None]).max())
+    assert np.abs(n(hx.float()).mean(1) - n(hi.float()).mean(1) + b0.mean()).max() < 0.05    # the extra offset never reaches the plane
+
+
 @pytest.mark.parametrize("offset,massive", [(0.0, 0), (2.0, 0), (2.0, 3), (50.0, 3)])
 def test_layernorm_fold_accuracy_with_row_offsets_and_massive_channels(offset, massive):
     """The folded LayerNorm normalises bf16(x) (the hi plane): x is rounded BEFORE the mean is subtracted, so a row whose common

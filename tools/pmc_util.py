@@ -37,7 +37,10 @@ def main(d, out):
             "mfma_util": round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8 * 1024) if v["GRBM_GUI_ACTIVE"] else 0.0, 4),
             "wait_any_frac": round(v["SQ_WAIT_ANY"] / wc, 3), "wait_inst_any_frac": round(v["SQ_WAIT_INST_ANY"] / wc, 3),
             "lds_bank_conflict_frac": round(v["SQ_LDS_BANK_CONFLICT"] / wc, 4),
+            # SQ_INSTS_VALU COUNTS the MFMA instructions themselves (8192^3 GEMM, whose K loop has no other VALU: 1.09,
+            # profiles/r04_gemm8192_pmc_insts_valu_includes_mfma.txt): the second figure is the non-matrix VALU per MFMA
             "valu_per_mfma": round(v["SQ_INSTS_VALU"] / v["SQ_INSTS_MFMA"], 2) if v["SQ_INSTS_MFMA"] else None,
+            "other_valu_per_mfma": round(v["SQ_INSTS_VALU"] / v["SQ_INSTS_MFMA"] - 1.0, 2) if v["SQ_INSTS_MFMA"] else None,
         }
     json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
                          "SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -- python3 bench.py "
