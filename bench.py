@@ -536,10 +536,11 @@ def thread_cpu_seconds():
 
 
 def blocking_sync(device_index):
-    """hipDeviceScheduleBlockingSync before the device context exists: torch.cuda.synchronize() then SLEEPS on an interrupt
-    instead of spinning (the default on a host with more cores than GPUs), so a rank that only waits for its GPU does not burn
-    a core -- eight ranks share the node's cores (16 in this pool's cgroup).  PM_BENCH_SPIN_SYNC=1 keeps the default."""
-    if os.environ.get("PM_BENCH_SPIN_SYNC") == "1":
+    """PM_BENCH_BLOCKING_SYNC=1 (opt-in): hipDeviceScheduleBlockingSync before the device context exists, so that EVERY wait of
+    the process sleeps on an interrupt instead of spinning.  Not the default: it also slows the host-paced drop-in generate()
+    measured in `extra` (0.6 ms of wake-up latency per saved image: 411 vs 454 images/s).  The timed loop does not need it:
+    its pacing waits are blocking events already, only the closing synchronize (<= PACE steps of work) spins."""
+    if os.environ.get("PM_BENCH_BLOCKING_SYNC") != "1":
         return
     try:
         import ctypes
@@ -710,38 +711,46 @@ def main():
     ru0 = resource.getrusage(resource.RUSAGE_SELF)      # process-wide: the main thread, lane threads, the HIP runtime's helpers
     th0 = thread_cpu_seconds()
     t0 = time.perf_counter()
-    # The host stays at most PACE steps ahead of the GPU: before step i is enqueued it SLEEPS (blocking event) until step
-    # i - PACE has finished.  Unpaced, the launch calls of a long run block on the full hardware queue and that wait spins:
-    # a whole core per rank for nothing (measured at 20 steps: 101 ms of CPU per 133 ms step).  Two steps (0.26 s of queued
-    # GPU work) of slack keep the GPU fed.
+    # The host stays at most PACE steps ahead of the GPU: before step i is enqueued it waits until step i - PACE has finished,
+    # and it waits QUIETLY (event.query() + a 1 ms sleep: on this ROCm a hipEventSynchronize spins even on a blocking event
+    # unless the whole device context is switched to blocking sync, which the profiler and the host-paced drop-in path both
+    # dislike).  Unpaced, the launch calls of a long run block on the full hardware queue and that wait spins as well: a whole
+    # core per rank for nothing.  Two steps (0.26 s of queued GPU work) of slack keep the GPU fed.
+    def wait_quietly(events):
+        for ev in events:
+            while not ev.query():
+                time.sleep(0.001)
+
     paced = []
     for i in range(args.steps):
         if len(paced) >= PACE:
-            for ev in paced.pop(0):
-                ev.synchronize()
+            wait_quietly(paced.pop(0))
         if free_running:
             parts = step(args.warmup + i, join=False)   # lanes keep their own stream order; device-wide sync below joins them
             if dist is not None:
                 gather_lanes(parts)
             evs = []
             for _, _, st in parts:
-                ev = torch.cuda.Event(blocking=True)
+                ev = torch.cuda.Event()
                 ev.record(st)
                 evs.append(ev)
             paced.append(evs)
         else:
             gather(step(args.warmup + i))
-            ev = torch.cuda.Event(blocking=True)
+            ev = torch.cuda.Event()
             ev.record()
             paced.append([ev])
     host_enqueue = time.perf_counter() - t0             # wall time until the last step is enqueued: INCLUDES the time the launch
     ru1 = resource.getrusage(resource.RUSAGE_SELF)      # calls block on a full hardware queue (back-pressure, not host work)
+    for evs in paced:
+        wait_quietly(evs)                               # the remaining <= PACE steps, without spinning
     drain_gathers()
     torch.cuda.synchronize(device)
     own_elapsed = time.perf_counter() - t0              # this rank's own K steps (before waiting for the slowest rank)
     ru2 = resource.getrusage(resource.RUSAGE_SELF)
     th1 = thread_cpu_seconds()
-    by_thread = sorted(((th1[t][1] - th0.get(t, (None, 0.0))[1], th1[t][0]) for t in th1), reverse=True)
+    by_thread = sorted(((th1[t][1] - th0.get(t, (None, 0.0))[1], "main" if t == os.getpid() else th1[t][0]) for t in th1), reverse=True)
+    main_cpu = th1.get(os.getpid(), (None, 0.0))[1] - th0.get(os.getpid(), (None, 0.0))[1]
     cpu_enqueue = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
     cpu_total = (ru2.ru_utime + ru2.ru_stime) - (ru0.ru_utime + ru0.ru_stime)   # incl. the closing synchronize (a spin or a sleep)
     if dist is not None:
@@ -774,13 +783,14 @@ def main():
         "self_check": "ok", "self_check_detail": detail,
         "rccl_ranks": dist.get_world_size() if dist is not None else 0,
         "per_rank_images_per_s": [round(B * args.steps / e, 3) for e in per_rank],
-        # HOST COST of one step.  host_cpu_ms_per_step: CPU time (user + system, getrusage over the whole process: main thread,
-        # lane threads, runtime helper threads) spent while the K steps were being enqueued -- what a rank takes from the
-        # node's cores.  host_cpu_ms_per_step_incl_sync adds the closing synchronize.  host_enqueue_wall_ms_per_step is wall
-        # time until the last step is enqueued and INCLUDES blocking on a full hardware queue (with K >> queue depth it
-        # approaches ms_per_step; it is not host work).
-        "host_cpu_ms_per_step": round(cpu_enqueue / args.steps * 1e3, 3),
-        "host_cpu_ms_per_step_incl_sync": round(cpu_total / args.steps * 1e3, 3),
+        # HOST COST of one step, measured (getrusage for the process, /proc/self/task for the threads), over the K timed steps
+        # including the closing synchronize.  host_main_thread_cpu_ms_per_step: the thread that enqueues (graph replays of the
+        # lanes, parameter copies, event records, pacing) -- the path's own host work.  host_cpu_ms_per_step: the whole
+        # process; the difference is the HIP runtime's helper threads, one of which busy-polls for as long as GPU work is
+        # outstanding (a full core whatever the wait policy).  host_enqueue_wall_ms_per_step: wall time until the last step is
+        # enqueued; it INCLUDES the pacing sleeps (the host stays <= PACE steps ahead), so it approaches ms_per_step.
+        "host_main_thread_cpu_ms_per_step": round(main_cpu / args.steps * 1e3, 3),
+        "host_cpu_ms_per_step": round(cpu_total / args.steps * 1e3, 3),
         "host_cpu_fraction_of_one_core": round(cpu_total / max(own_elapsed, 1e-9), 4),
         "host_enqueue_wall_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
         "host_cpu_ms_per_step_by_thread": [{"thread": nm, "cpu_ms_per_step": round(sec / args.steps * 1e3, 2)} for sec, nm in by_thread[:4] if sec > 0],
