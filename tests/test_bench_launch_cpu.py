@@ -35,3 +35,24 @@ def test_mismatched_world_size_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "launch-selftest", "--gpus", "2"],
                        capture_output=True, text=True, timeout=300, env=e)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_work_accounting_is_consistent():
+    """bench.py's per-kernel-kind flops (roofline_by_kernel) add up to the GEMM total that roofline_gemm_family uses, for every
+    workload; the residual producers' algorithmic bytes are the A operand + the pair in + out."""
+    import bench
+    for wl in ("maskgit-uncond-12L-d512-T8", "maskgit-text-24L-d768-T8", "maskgit-text-24L-d1024-512px-T18", "vit-s-recon"):
+        kinds = {}
+        gf, af, _ = bench.work_per_step(wl, kinds=kinds)
+        by_kind = sum(v for k, v in kinds.items() if k.startswith("gemm_"))
+        cfg_name, B, T, L = bench.WORKLOADS[wl]
+        if cfg_name is None:
+            assert abs(gf - by_kind - B * 2 * 1024 * 32 * 8192) < 1e-6 * gf          # the VQ distance product is not a GEMM launch
+        elif L is None:
+            assert abs(gf - by_kind) < 1e-9 * gf
+        else:
+            assert 0 < gf - by_kind < 0.02 * gf      # the context K / V + context_proj: per step in the totals, once per loop in the kinds
+        assert af > 0 and kinds["bytes_resid2b"] > 0
+    kinds = {}
+    bench.layer_flops(512, 8, 2048, 1024, False, None, kinds)
+    assert kinds["bytes_resid2b"] == 1024 * (512 * 2 + 512 * 8) and kinds["bytes_resid"] == 1024 * (1368 * 2 + 512 * 8)

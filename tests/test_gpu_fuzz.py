@@ -163,3 +163,39 @@ def test_fuzz_rows(seed):
     loss, rows = ops.masked_ce(t(logits), t(labels), t(msk), 0.1)
     lo, ro = O.masked_ce(logits, labels, msk, 0.1)
     assert abs(float(loss) - float(lo)) < 1e-4 and np.abs(n(rows) - ro).max() < 1e-4
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_gemm_hilo_center(seed):
+    """pmhip_gemm_hilo_center at random shapes over every kernel route: the centred pair + the accumulated shift reproduce the
+    float64 x_new; the shift equals the previous plane's row mean + center_extra; a second producer chained on the first keeps
+    the identity (the shift accumulates)."""
+    r = _rng(400 + seed)
+    bf = torch.bfloat16
+    if seed < 4:
+        M, N, K = int(r.choice([1, 100, 300, 777, 2048])), 64 * int(r.integers(1, 9)), 64 * int(r.integers(1, 9))
+    else:
+        M, N, K = 256 * int(r.integers(24, 100)), int(r.choice([256, 512, 768, 1024])), 64 * int(r.integers(1, 25))
+    a = bf16_round(r.standard_normal((M, K)).astype(np.float32) * 0.7)
+    w = bf16_round((r.standard_normal((N, K)) * K ** -0.5).astype(np.float32))
+    b0 = r.standard_normal(N).astype(np.float32)
+    off = float(r.choice([0.0, 3.0, 40.0]))
+    res = (r.standard_normal((M, N)) * 1.2 + off + r.standard_normal((M, 1))).astype(np.float32)
+    rh, rl = ops.split_hilo(t(res))
+    x = n(ops.join_hilo(rh, rl)).astype(np.float64)
+    shift = torch.zeros(M, device=dev())
+    extra = float(np.float32(b0.mean()))
+    tot_shift = np.zeros(M)
+    hi, lo = rh, rl
+    for rep in range(2):
+        coef = ops.ln_coef(hi)
+        cen = -n(coef)[:, 1].astype(np.float64) / n(coef)[:, 0].astype(np.float64) + extra
+        x = a.astype(np.float64) @ w.astype(np.float64).T + b0 + x
+        hi, lo = ops.gemm_hilo_center(t(a, bf), t(w, bf), hi, lo, bias=t(b0), center_coef=coef, shift=shift, shift_mode=2, center_extra=extra)
+        tot_shift += cen
+        sh = n(shift).astype(np.float64)
+        assert np.abs(sh - tot_shift).max() < 1e-4 * max(1.0, np.abs(tot_shift).max()), (rep, M, N, K)
+        got = n(ops.join_hilo(hi, lo)).astype(np.float64) + sh[:, None]
+        scale = max(1.0, np.abs(x - sh[:, None]).max())
+        assert np.abs(got - x).max() < 4e-5 * scale * (rep + 1), (rep, M, N, K, np.abs(got - x).max())
+        x = got                                              # chain on what the planes really hold

@@ -616,3 +616,20 @@ def test_streamed_kernels_are_bit_stable_over_repetitions():
         assert torch.equal(q, q0) and torch.equal(k, k0) and torch.equal(v, v0), i
         assert torch.equal(o, o0), i
         assert torch.equal(h, h0) and torch.equal(l, l0), i
+
+
+def test_guidance_combine_is_one_fma_per_element():
+    """pmhip_guidance_combine: out = fmaf(scale, cond - uncond, uncond) in fp32, in place allowed, scale 0 / 1 edge cases"""
+    g = torch.Generator().manual_seed(3)
+    c = torch.randn(5, 1024, 512, generator=g).to(dev()) * 4
+    u = torch.randn(5, 1024, 512, generator=g).to(dev()) * 4
+    for scale in (0.0, 1.0, 2.5, -0.75):
+        out = ops.guidance_combine(c, u, scale)
+        diff = (c - u).double()                              # the fp32 difference, exactly representable in float64
+        want = (diff * float(np.float32(scale)) + u.double()).float()     # one rounding of the exact fused result
+        assert torch.equal(out, want), scale
+    assert torch.equal(ops.guidance_combine(c, u, 0.0), u)
+    c2 = c.clone()
+    assert ops.guidance_combine(c2, u, 2.5, out=c2) is c2 and torch.equal(c2, ops.guidance_combine(c, u, 2.5))
+    with pytest.raises(ValueError):
+        ops.guidance_combine(c, u[:4], 1.0)
