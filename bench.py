@@ -535,6 +535,47 @@ def thread_cpu_seconds():
     return out
 
 
+class PowerSampler:
+    """Best-effort package power / shader clock of this rank's GPU during the timed region (`rocm-smi` polled from a thread,
+    about two samples per second; the subprocess waits outside the GIL).  The decode loop runs at the socket power cap
+    (DESIGN.md section 4f): the line carries the evidence.  Never raises; `summary()` is None when nothing could be read."""
+
+    def __init__(self, device_index):
+        import threading
+        self.dev, self.samples, self.stop = device_index, [], threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        while not self.stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showpower", "--showclocks"], capture_output=True, text=True,
+                                     timeout=3).stdout
+                pw = re.search(r"Power \(W\): ([\d.]+)", out)
+                ck = re.search(r"sclk clock level: \S+ \((\d+)Mhz", out)
+                if pw and ck:
+                    self.samples.append((float(pw.group(1)), float(ck.group(1))))
+            except Exception:
+                return
+            self.stop.wait(0.35)
+
+    def start(self):
+        if os.environ.get("PM_BENCH_NO_POWER") != "1":
+            self.thread.start()
+        return self
+
+    def summary(self):
+        self.stop.set()
+        if self.thread.is_alive():
+            self.thread.join(timeout=4)
+        s = self.samples[1:] if len(self.samples) > 2 else self.samples       # the first sample may predate the load
+        if not s:
+            return None
+        return {"package_watts_mean": round(sum(x[0] for x in s) / len(s), 1), "package_watts_max": max(x[0] for x in s),
+                "sclk_mhz_mean": round(sum(x[1] for x in s) / len(s)), "samples": len(s),
+                "note": "rocm-smi during the timed region; the socket cap of this part is 1400 W, the nominal shader clock 2400 MHz"}
+
+
 def blocking_sync(device_index):
     """PM_BENCH_BLOCKING_SYNC=1 (opt-in): hipDeviceScheduleBlockingSync before the device context exists, so that EVERY wait of
     the process sleeps on an interrupt instead of spinning.  Not the default: it also slows the host-paced drop-in generate()
@@ -708,6 +749,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
+    power = PowerSampler(local_rank).start() if rank == 0 else None
     ru0 = resource.getrusage(resource.RUSAGE_SELF)      # process-wide: the main thread, lane threads, the HIP runtime's helpers
     th0 = thread_cpu_seconds()
     t0 = time.perf_counter()
@@ -749,6 +791,7 @@ def main():
     own_elapsed = time.perf_counter() - t0              # this rank's own K steps (before waiting for the slowest rank)
     ru2 = resource.getrusage(resource.RUSAGE_SELF)
     th1 = thread_cpu_seconds()
+    power_summary = power.summary() if power is not None else None
     by_thread = sorted(((th1[t][1] - th0.get(t, (None, 0.0))[1], "main" if t == os.getpid() else th1[t][0]) for t in th1), reverse=True)
     main_cpu = th1.get(os.getpid(), (None, 0.0))[1] - th0.get(os.getpid(), (None, 0.0))[1]
     cpu_enqueue = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
@@ -794,6 +837,7 @@ def main():
         "host_cpu_fraction_of_one_core": round(cpu_total / max(own_elapsed, 1e-9), 4),
         "host_enqueue_wall_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
         "host_cpu_ms_per_step_by_thread": [{"thread": nm, "cpu_ms_per_step": round(sec / args.steps * 1e3, 2)} for sec, nm in by_thread[:4] if sec > 0],
+        "power": power_summary,
         "per_rank_host_cpu_ms_per_step": [round(c[1] / args.steps * 1e3, 3) for c in per_rank_cpu],
         # the path's only collective: finished images of one step -> rank 0 (0 without a process group)
         "gather_bytes_per_step_per_rank": (B * 3 * 256 * 256 * 4 if cfg0 is None else B * 3 * img_px * img_px * 4) if dist is not None else 0,
