@@ -49,13 +49,16 @@ WORKLOADS = {
     "maskgit-text-24L-d768-T8": ("bench-text-24L-d768", 32, 8, 77),            # north_star target model, 8 steps
     "maskgit-text-24L-d768-T12": ("bench-text-24L-d768", 32, 12, 77),          # BASELINE configs[3] per-GPU share
     "maskgit-text-24L-d1024-512px-T18": ("bench-text-24L-d1024-512px", 64, 18, 77),   # BASELINE configs[4] per-GPU share
+    # the reference's ONLY pipeline preset (config.py:70-82, the default of factory.py:6): 12L / d1024 / 16 heads, T5-L features of
+    # width 1024 (context_proj = Identity), at the reference's default 18 steps; the T5 tower is replaced by synthetic features
+    "paintmindv1-T18": ("paintmindv1", 32, 18, 77),
     "vit-s-recon": (None, 64, 0, None),                                         # BASELINE configs[1]
     "launch-selftest": (None, 4, 0, None),     # no compute: exercises the rank launcher / gather / JSON relay on CPU (gloo)
 }
 # measured after the headline, outside its timed region, each with its own ms_per_step ("extra" in the JSON line)
 EXTRA_WORKLOADS = [("maskgit-text-24L-d768-T8", "bf16", 3), ("maskgit-text-24L-d768-T12", "bf16", 3), ("vit-s-recon", "bf16", 5),
                    ("maskgit-text-24L-d1024-512px-T18", "bf16", 2), (DEFAULT_WORKLOAD, "fp32", 2),
-                   ("maskgit-text-24L-d768-T8", "fp32", 1)]      # the north_star model in the mode parity is graded in (target >= 20 images/s)
+                   ("maskgit-text-24L-d768-T8", "fp32", 1), ("paintmindv1-T18", "bf16", 2)]      # the north_star model in the mode parity is graded in (target >= 20 images/s)
 
 
 def log(msg):
@@ -166,8 +169,9 @@ def s2_step_flops(cfg, N, embed_dim, n_embed, ctx_len, kinds=None, times=1, loop
         if ctx_len is not None:
             inner = cfg["num_head"] * 64
             kinds["gemm_heads"] += loops * cfg["depth"] * 2 * 2 * ctx_len * cfg["dim"] * inner
-            if cfg.get("context_dim", cfg["dim"]) != cfg["dim"]:
-                kinds["gemm_plain"] += loops * 2 * ctx_len * cfg["context_dim"] * cfg["dim"]
+            cdim = cfg.get("context_dim") or {"t5-l": 1024, "t5-xl": 2048}[cfg["t5"]]
+            if cdim != cfg["dim"]:
+                kinds["gemm_plain"] += loops * 2 * ctx_len * cdim * cfg["dim"]
     return gemm, attn
 
 
@@ -207,9 +211,20 @@ def build(workload, device, dtype):
         model = pm.create_model(arch="vqgan", version="vit-s-vqgan", pretrained=False).to(device).eval()
         model.set_compute_dtype(dtype)
         return model
-    pipe = Pipeline(pm.Config(ver2cfg[cfg_name]), stage1_pretrained=False).to(device).eval()
+    text_model = None
+    if "text_model" not in ver2cfg[cfg_name]:               # a reference preset: its T5 tower is a download, stand in for it
+        from paintmind_amd.modules.encoder import SyntheticTextEmbedder
+        text_model = SyntheticTextEmbedder(context_dim_of(cfg_name))
+    pipe = Pipeline(pm.Config(ver2cfg[cfg_name]), stage1_pretrained=False, text_model=text_model).to(device).eval()
     pipe.set_compute_dtype(dtype)
     return pipe
+
+
+def context_dim_of(cfg_name):
+    from paintmind_amd.config import ver2cfg
+    from paintmind_amd.generate import T5_TXT_DIM
+    cfg = ver2cfg[cfg_name]
+    return cfg.get("context_dim") or T5_TXT_DIM[cfg["t5"]]
 
 
 def lanes_arg(streams=None):
@@ -235,7 +250,7 @@ def make_step(workload, model, device, rank, decode_every_step=True):
     ctx = None
     if L is not None:
         g = torch.Generator().manual_seed(1234 + rank)
-        ctx = torch.randn(B, L, ver2cfg[cfg_name]["context_dim"], generator=g).to(device)
+        ctx = torch.randn(B, L, context_dim_of(cfg_name), generator=g).to(device)
     flags = [True] * T if decode_every_step else [t == T - 1 for t in range(T)]
 
     def step(i, join=True, streams=None):
@@ -459,7 +474,7 @@ def cpu_baseline(workload):
 
         def run(Bc, steps):
             ids = torch.full((Bc, N), vq["n_embed"], dtype=torch.long)
-            ctx = None if L is None else torch.randn(Bc, L, ver2cfg[cfg_name]["context_dim"])
+            ctx = None if L is None else torch.randn(Bc, L, context_dim_of(cfg_name))
             t0 = time.perf_counter()
             for step in steps:
                 noise = torch.rand(Bc, N, vq["n_embed"])
