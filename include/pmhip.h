@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PMHIP_ABI_VERSION 8
+#define PMHIP_ABI_VERSION 9
 
 enum { PMHIP_OK = 0, PMHIP_EINVAL = 1, PMHIP_EHIP = 2, PMHIP_ENOMEM = 3, PMHIP_ESTATE = 4 };
 enum { PMHIP_F32 = 0, PMHIP_BF16 = 1 };
@@ -149,6 +149,14 @@ int pmhip_lnfold_supported(int dtype, int epi_kind, int M, int N, int K);
 int pmhip_attention(int dtype, const void* Q, const void* K, const void* Vt, void* out, int ldo,
                     int B, int heads, int Nq, int Nkv, int Nkv_pad, int use_exp2,
                     pmhip_stream stream);
+
+/* Diagnostic of the bf16 kernel behind pmhip_attention (round 5).  Its fast path measures every probability against the
+ * maximum of the query's first 32 keys and never looks at the running maximum again; a workgroup in which a probability
+ * left the f32 range (scores more than 2^6 octaves above that reference; the softmax of modules/attention.py:53 itself
+ * has no such limit) notices it when it normalises and runs again through its exact path, which raises the running
+ * maximum at every half-tile.  *count = such workgroups on the current device since the last reset (synchronises the
+ * device). */
+int pmhip_attention_fallbacks(unsigned long long* count, int reset);
 
 /* ---- any dim_head (modules/attention.py:27-33: inner_dim = dim_head * heads, scale = dim_head^-0.5).  The reference's
  * configs all use 64 and the tuned kernels above are built for it; these entry points forward to them when

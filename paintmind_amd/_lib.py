@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpaintmind_hip.so")
 PMHIP_OK = 0
 F32, BF16 = 0, 1
 PART_Q, PART_K, PART_V = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 vp = C.c_void_p
 i32 = C.c_int
@@ -89,6 +89,7 @@ PROTOTYPES = {
                                   C.POINTER(vp), f32, C.POINTER(LnFold), vp]),
     "pmhip_lnfold_supported": (i32, [i32, i32, i32, i32, i32]),
     "pmhip_attention": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "pmhip_attention_fallbacks": (i32, [C.POINTER(C.c_ulonglong), i32]),
     "pmhip_gemm_heads_dh": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32),
                                   C.POINTER(vp), f32, vp, vp]),
     "pmhip_attention_dh": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

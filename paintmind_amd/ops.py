@@ -286,6 +286,16 @@ def gemm_heads_ln(xb, wg, heads, tokens, kinds, q_scale, coef, c, d):
     return outs
 
 
+def attention_fallbacks(reset=False, device=None):
+    """Workgroups of the bf16 attention kernel that had to be run again through its exact path since the last reset
+    (a probability of the fixed-reference fast path left the f32 range; include/pmhip.h)."""
+    lib = _lib.load()
+    n = C.c_ulonglong(0)
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        check(lib.pmhip_attention_fallbacks(C.byref(n), int(bool(reset))), "pmhip_attention_fallbacks")
+    return int(n.value)
+
+
 def attention(q, k, vt, n_kv, use_exp2=False):
     """q [B,H,Nq,dh], k [B,H,Nkp,dh], vt [B,H,dh,Nkp] -> [B*Nq, H*dh]  (dh 64: tuned MFMA kernel; else pmhip_attention_dh)."""
     dev = _dev(q, k, vt)

@@ -367,10 +367,13 @@ def test_heads_projection_and_attention(dtype, B, heads, Nq, Nkv):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("pattern", ["rising", "falling", "spikes", "huge_jumps", "very_negative"])
-def test_attention_running_max_rescale_paths(dtype, pattern):
-    """Scores whose maximum keeps growing along the key axis (every deferred-rescale branch of the online softmax fires,
-    including jumps far beyond the exp2 range), shrinking, with isolated spikes, and all very negative."""
-    B, H, Nq, Nkv = 1, 2, 256, 416                       # 6.5 tiles: ragged last tile, odd number of half-tiles
+@pytest.mark.parametrize("Nkv", [416, 448])
+def test_attention_running_max_rescale_paths(dtype, pattern, Nkv):
+    """Scores whose maximum keeps growing along the key axis, including jumps far beyond the exp2 range (the bf16 kernel's
+    fixed-reference fast path overflows and the workgroup must notice and take its exact path), shrinking, with isolated
+    spikes, and all very negative.  Nkv = 416: 6.5 tiles, ragged last tile, odd number of half-tiles (fast steps, then exact
+    steps); 448: whole tiles only (every half-tile through the fast step)."""
+    B, H, Nq = 1, 2, 256
     rng = np.random.default_rng(7)
     q = rng.standard_normal((B, H, Nq, 64)).astype(np.float32)
     k = rng.standard_normal((B, H, Nkv, 64)).astype(np.float32) * 0.3
@@ -409,11 +412,48 @@ def test_attention_running_max_rescale_paths(dtype, pattern):
     kp[:, :, :Nkv] = k
     vtp = np.zeros((B, H, 64, nkp), np.float32)
     vtp[:, :, :, :Nkv] = v.transpose(0, 1, 3, 2)
+    if fast:
+        ops.attention_fallbacks(reset=True)
     out = n(ops.attention(t(qs, dtype), t(kp, dtype), t(vtp, dtype), Nkv, use_exp2=fast))
     assert np.isfinite(out).all()
     # scores of ~1e4 carry an fp32 ulp of ~1e-3 themselves: any fp32 softmax is only that accurate against float64
     tol32 = 2e-3 if pattern == "huge_jumps" else 5e-5
     assert rel_err(out, ref) < (tol32 if dtype == torch.float32 else 4e-2), rel_err(out, ref)
+    if fast:
+        # the exact path ran where, and only where, the scores leave the fast path's range (B*H = 2 workgroups here):
+        # huge_jumps climbs by hundreds of octaves per 50 keys; the other patterns stay within 2^64 of the first keys' maximum
+        fb = ops.attention_fallbacks(reset=True)
+        assert fb == (2 if pattern == "huge_jumps" else 0), fb
+
+
+def test_attention_fallback_is_per_workgroup_and_matches_the_exact_result():
+    """One (batch, head) of eight carries a key that overflows the fast path: exactly its query blocks are redone, the other
+    heads are untouched bit for bit, and the redone head equals what the exact path gives on its own (Nkv = 100 is ragged and
+    below three tiles: exact path only)."""
+    B, H, N = 2, 4, 512
+    rng = np.random.default_rng(11)
+    q = bf16_round(rng.standard_normal((B, H, N, 64)).astype(np.float32) * 0.3)
+    k = bf16_round(rng.standard_normal((B, H, N, 64)).astype(np.float32))
+    v = bf16_round(rng.standard_normal((B, H, N, 64)).astype(np.float32))
+    vt = np.ascontiguousarray(v.transpose(0, 1, 3, 2))
+    ops.attention_fallbacks(reset=True)
+    base = n(ops.attention(t(q, torch.bfloat16), t(k, torch.bfloat16), t(vt, torch.bfloat16), N, use_exp2=True))
+    assert ops.attention_fallbacks(reset=True) == 0
+    k2 = k.copy()
+    k2[1, 2, 300] = bf16_round(q[1, 2, 5] * 4000.0)       # a key aligned with one query: ~ +1e4 octaves for that row, large for the others
+    out = n(ops.attention(t(q, torch.bfloat16), t(k2, torch.bfloat16), t(vt, torch.bfloat16), N, use_exp2=True))
+    fb = ops.attention_fallbacks(reset=True)
+    assert 1 <= fb <= N // 256, fb                          # only query blocks of (b=1, h=2)
+    assert np.isfinite(out).all()
+    o4, b4 = out.reshape(B, N, H, 64), base.reshape(B, N, H, 64)
+    mask = np.ones((B, H), bool)
+    mask[1, 2] = False
+    assert all(np.array_equal(o4[b, :, h], b4[b, :, h]) for b in range(B) for h in range(H) if mask[b, h])
+    s = (q[1, 2].astype(np.float64) @ k2[1, 2].astype(np.float64).T) * np.log(2.0)
+    s -= s.max(-1, keepdims=True)
+    pr = np.exp(s)
+    pr /= pr.sum(-1, keepdims=True)
+    assert rel_err(o4[1, :, 2], pr @ v[1, 2].astype(np.float64)) < 4e-2
 
 
 def test_attention_ignores_garbage_in_padding():

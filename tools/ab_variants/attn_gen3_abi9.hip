@@ -18,18 +18,6 @@
 //      A: 16 MFMAs of S^T(h+1)          with the 32 exponentials + 16 bf16 packs of S^T(h)
 //      B: 20 MFMAs of P.V(h) + l(h)     with the 16 v_max3 of S^T(h+1)
 //    V^T fragments of h are requested before block A, K fragments of h+2 before block B, so no LDS latency is exposed.
-//
-// Fourth generation (round 5): the steady loop has NO running-max bookkeeping at all.
-//  * The reference max of a query is fixed after the first 32-key half-tile; every later probability is 2^(s - m_ref),
-//    whatever its size.  bf16 P and the f32 accumulators have the exponent range of f32, so nothing is lost until a
-//    probability overflows -- which the epilogue detects POST HOC (l not below 2^64, NaN included) and answers by running the
-//    whole workgroup again through the exact path (running max raised at every half-tile: the rare-path code that ragged and
-//    short contexts use anyway).  Round 4 counted the old growth branch on real data: 0 executions in 134 M steps, while
-//    its detector was 16 of the 69 vector instructions of a half-tile.
-//  * S^T is single-buffered and the half-tile is walked QUERY-TILE-major: group g issues the 4 QK^T MFMAs of S^T(h+1, g)
-//    (overwriting S^T(h, g), whose exponentials were issued one group earlier), the 4 P.V MFMAs + the row-sum MFMA of
-//    (h, g), and the 8 exponentials + 4 packs of (h, g+1).  Every group is 9 MFMAs beside 12 vector instructions: the
-//    vector work is spread evenly under ALL matrix instructions (third generation: 3 per MFMA in block A, none in B).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -40,24 +28,9 @@
 #define ABL 0                 // ablation bit mask (tools/hwtests/attn_abl.hip); 0 in the library
 #endif
 
-// workgroups whose fast path overflowed and that were run again through the exact path (pmhip_attention_fallbacks)
-__device__ unsigned long long g_attn_fallbacks;
-#ifndef PM_ATTN_NO_ABI           // tools/hwtests/attn_ab.hip compiles this file several times in one program
-extern "C" int pmhip_attention_fallbacks(unsigned long long* count, int reset) {
-    PM_REQUIRE(count != nullptr, "pmhip_attention_fallbacks: count is NULL");
-    PM_HIP(hipDeviceSynchronize());
-    PM_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_attn_fallbacks), sizeof(unsigned long long)));
-    if (reset) {
-        const unsigned long long z = 0;
-        PM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_fallbacks), &z, sizeof(z)));
-    }
-    return PMHIP_OK;
-}
-#endif
-
 #ifdef PM_ATTN_COUNT
 // DEBUG BUILD ONLY (tools/attn_rescale_count.sh): how often the steady loop leaves its fast path on real data.
-// [1] fast half-tile steps (per wave), [2] exact steps
+// [0] wave-level executions of the rescale branch inside the steady loop, [1] steady half-tile steps (per wave), [2] slow steps
 __device__ unsigned long long g_attn_counters[4];
 extern "C" int pmhip_debug_attention_counters(unsigned long long* out4, int reset) {
     if (out4 && hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_attn_counters), 32) != hipSuccess) return 1;
@@ -66,6 +39,7 @@ extern "C" int pmhip_debug_attention_counters(unsigned long long* out4, int rese
 }
 #endif
 
+extern "C" int pmhip_attention_fallbacks(unsigned long long* count, int) { *count = 0; return 0; }
 namespace {
 
 constexpr int KT = 64;        // keys per tile
@@ -74,12 +48,6 @@ constexpr int THREADS = 256;
 constexpr int QF = 4;         // 16-query tiles per wave
 constexpr int TILE_BYTES = KT * 128;
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;              // K tile + V^T tile
-#ifndef PM_ATTN_RING
-#define PM_ATTN_RING 4
-#endif
-constexpr int RING = PM_ATTN_RING;       // ring stages: a tile is requested RING - 2 tiles before it is entered (round 5: 4;
-                                         // with 3 the DMA had ONE tile period, about 1 us, to come back from HBM)
-constexpr int AHEAD = RING - 2;
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
@@ -101,7 +69,8 @@ template <bool EXP2>
 __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
                                                                     const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
                                                                     int ldo, int heads, int Nq, int Nkv, int Nkv_pad, int nqb) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[RING * STAGE_BYTES];   // K / V^T ring
+    constexpr float kDefer = EXP2 ? 8.0f : 0.0f;             // skip the O rescale while the row max grows < 2^8
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE_BYTES];   // 3-stage K / V^T ring
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -147,7 +116,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
     // one K tile + one V^T tile by DMA, 1 KiB per wave-instruction; the bank swizzle (slot ^ row) is applied to the SOURCE
     // address (kvoff / vvoff) and again on the read side
     auto stage_tiles = [&](int t) {
-        unsigned char* stage = lds + (t % RING) * STAGE_BYTES;
+        unsigned char* stage = lds + (t % 3) * STAGE_BYTES;
         const unsigned kv0 = (unsigned)t * KT;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -175,7 +144,14 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
 
     f32x4_t o[4][QF];
     f32x4_t lacc[QF];                    // every element = l of the query column (sum of bf16 P, by MFMA with a ones operand)
-    f32x4_t negm[QF];                    // -m (reference max of the query column) x4: the C operand of the S^T MFMAs
+    f32x4_t negm[QF];                    // -m (running max of the query column) x4: the C operand of the S^T MFMAs
+#pragma unroll
+    for (int j = 0; j < QF; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        lacc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        negm[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     v4u_t ones = v4u_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     asm volatile("" : "+v"(ones));       // keep it in registers (not re-materialised in front of every use)
 
@@ -183,12 +159,12 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
     const int nhalves = (Nkv + 31) / 32;                     // 32-key half-tiles that contain at least one valid key
 
     auto k_issue = [&](v4u_t (&kf)[2][2], int hh) {
-        const unsigned ka = kfrag_lane + (unsigned)((hh >> 1) % RING) * STAGE_BYTES + (unsigned)(hh & 1) * 4096u;
+        const unsigned ka = kfrag_lane + (unsigned)((hh >> 1) % 3) * STAGE_BYTES + (unsigned)(hh & 1) * 4096u;
         DSRX(kf[0][0], ka, 0 * 512 + 0 * 64); DSRX(kf[0][1], ka, 0 * 512 + 1 * 64);
         DSRX(kf[1][0], ka, 1 * 512 + 1 * 64); DSRX(kf[1][1], ka, 1 * 512 + 0 * 64);
     };
     auto v_issue = [&](v4u_t (&vf)[4], int hh) {
-        const unsigned va = ((hh & 1) ? vfrag_lane1 : vfrag_lane0) + (unsigned)((hh >> 1) % RING) * STAGE_BYTES;
+        const unsigned va = ((hh & 1) ? vfrag_lane1 : vfrag_lane0) + (unsigned)((hh >> 1) % 3) * STAGE_BYTES;
         DSRX(vf[0], va, 0 * 2048); DSRX(vf[1], va, 1 * 2048); DSRX(vf[2], va, 2 * 2048); DSRX(vf[3], va, 3 * 2048);
     };
 
@@ -252,21 +228,15 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
 
     // entering tile tn (called while the previous tile's second half is still to be consumed): its DMA has landed
     // and is published by the barrier; the barrier also proves every wave is done with tile tn-2, whose stage the
-    // DMA of tile tn+AHEAD now reuses (RING stages: tn-2 and tn+AHEAD share one)
+    // DMA of tile tn+1 now reuses (3-stage ring)
     auto enter_tile = [&](auto ragged_c, int tn) {
         if (!(ABL & 8) || tn == 0) {
-            // this wave's pieces of tile tn have landed: everything but the pieces of the younger tiles in flight behind them
-            // (4 instructions per tile; vmcnt retires in issue order)
-            // The barrier is the bare instruction: __syncthreads() carries a fence, for which hipcc drains vmcnt to 0 -- that
-            // would wait for the younger tile as well.  Nothing else needs the fence here: the fast path reads LDS with
-            // inline-asm ds_read only, and the exact path's V^T patch below is followed by a full __syncthreads().
-            if (AHEAD == 2 && tn + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        if (tn + AHEAD < ntiles && !(ABL & 4)) stage_tiles(tn + AHEAD);
+        if (tn + 1 < ntiles && !(ABL & 4)) stage_tiles(tn + 1);
         if (decltype(ragged_c)::value && tn * KT + KT > Nkv) {   // ragged last tile: zero the V^T columns of keys >= Nkv
-            unsigned char* Vl = lds + (tn % RING) * STAGE_BYTES + TILE_BYTES;
+            unsigned char* Vl = lds + (tn % 3) * STAGE_BYTES + TILE_BYTES;
             for (int idx = tid; idx < KT * 8; idx += THREADS) {
                 const int row = idx / 8, ls = idx % 8;
                 uint4* p = reinterpret_cast<uint4*>(Vl + row * 128 + ((ls ^ (row & 7)) << 4));
@@ -282,21 +252,24 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
         }
     };
 
-    f32x4_t sA[2][QF];                   // S^T of ONE half-tile (single-buffered: group g of a step overwrites the tile it has consumed)
+    f32x4_t sA[2][QF], sB[2][QF];
     v4u_t pf[QF];
     v4u_t kf[2][2], vf[4];
 
-    // exponentials of the 16-query tile qf of S^T(h) and their packing into the P^T operand; S^T itself is left as it is
-    auto exp_pack1 = [&](f32x4_t (&sc)[2][QF], int qf) {
-        float e[2][4];
+    // exponentials of the 16-query tiles qa, qa+1 of S^T(h) (in place) and their packing into the P^T operand
+    auto exp_pack = [&](f32x4_t (&sc)[2][QF], int qa) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int qf = qa; qf < qa + 2; ++qf) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                e[kk][r] = (ABL & 1) ? sc[kk][qf][r] * 1.0001f : (EXP2 ? __builtin_amdgcn_exp2f(sc[kk][qf][r]) : expf(sc[kk][qf][r]));   // sc = s - m
-        pf[qf] = v4u_t{pack_bf16x2(e[0][0], e[0][1]), pack_bf16x2(e[0][2], e[0][3]), pack_bf16x2(e[1][0], e[1][1]), pack_bf16x2(e[1][2], e[1][3])};
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sc[kk][qf][r] = (ABL & 1) ? sc[kk][qf][r] * 1.0001f : (EXP2 ? __builtin_amdgcn_exp2f(sc[kk][qf][r]) : expf(sc[kk][qf][r]));   // sc = s - m
+            pf[qf] = v4u_t{pack_bf16x2(sc[0][qf][0], sc[0][qf][1]), pack_bf16x2(sc[0][qf][2], sc[0][qf][3]),
+                           pack_bf16x2(sc[1][qf][0], sc[1][qf][1]), pack_bf16x2(sc[1][qf][2], sc[1][qf][3])};
+        }
     };
-    // P.V for two 16-row blocks of O^T and two of the four row-sum tiles (exact path)
+    // P.V for two 16-row blocks of O^T and two of the four row-sum tiles
     auto pv2 = [&](int d0) {
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) o[d0][qf] = mma(vf[d0], pf[qf], o[d0][qf]);
@@ -305,172 +278,154 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
         lacc[d0] = mma(ones, pf[d0], lacc[d0]);
         lacc[d0 + 1] = mma(ones, pf[d0 + 1], lacc[d0 + 1]);
     };
+    // growth check: max over the lane's 16 scores of S^T tile kk as SIGNED INTEGERS (exact whenever the maximum is >= 0,
+    // negative otherwise: all the comparison against the threshold needs; no NaN canonicalisation, plain VALU)
+    auto imax16 = [&](f32x4_t (&sn)[2][QF], int kk, int m) {
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            m = max(max(m, __float_as_int(sn[kk][qf][0])), __float_as_int(sn[kk][qf][1]));
+            m = max(max(m, __float_as_int(sn[kk][qf][2])), __float_as_int(sn[kk][qf][3]));
+        }
+        return m;
+    };
 
-    // One half-tile h of the FAST path, query-tile-major.  On entry sA = S^T(h) - m_ref (tiles 1..3 untouched, tile 0 already
-    // turned into pf[0]), the K fragments of h+1 and then the V^T fragments of h are in flight (in that order).  Group g:
-    //     matrix:  S^T(h+1, g) = K(h+1) Q_g - m_ref   (4 MFMAs, overwrites S^T(h, g))
-    //              O^T(., g) += V^T(h) P(h, g),  l_g += 1 P(h, g)                    (5 MFMAs)
-    //     vector:  P(h, g+1) = bf16(exp2(S^T(h, g+1)))  -- for g = 3: P(h+1, 0), from the S^T(h+1, 0) of this step's group 0
-    // The K fragments of h+2 are requested behind the last QK^T MFMA, the V^T fragments of h+1 behind the last P.V MFMA.
+    // One half-tile h in the steady state (h+1 and h+2 exist, h+1 lies in a full tile).  On entry sc = S^T(h) - m, already
+    // checked against growth, and the K fragments of h+1 are in flight (kf[0][*] older than kf[1][*]).  The K and V^T
+    // fragments time-share registers: V^T of h is requested as the K fragments of h+1 are consumed, K of h+2 as V^T is.
+    // Every wait is lgkmcnt(2): two reads older and two reads younger than the ones needed are outstanding.
     //   OPENS: h+2 is the first half of a new tile
-    auto grp_mma = [&](f32x4_t (&sc)[2][QF], int g) {
-        sc[0][g] = mma(kf[0][0], qreg[g][0], negm[g]);
-        sc[1][g] = mma(kf[1][0], qreg[g][0], negm[g]);
-        sc[0][g] = mma(kf[0][1], qreg[g][1], sc[0][g]);
-        sc[1][g] = mma(kf[1][1], qreg[g][1], sc[1][g]);
-    };
-    auto grp_pv = [&](int g) {
+    auto step = [&](auto opens_c, f32x4_t (&sc)[2][QF], f32x4_t (&sn)[2][QF], int hh) {
+        constexpr bool OPENS = decltype(opens_c)::value;
+        const unsigned va = ((hh & 1) ? vfrag_lane1 : vfrag_lane0) + (unsigned)((hh >> 1) % 3) * STAGE_BYTES;
+        const unsigned ka = kfrag_lane + (unsigned)(((hh + 2) >> 1) % 3) * STAGE_BYTES + (unsigned)(hh & 1) * 4096u;
+        // ---- A1: first key tile of S^T(h+1) under the exponentials of query tiles 0, 1
+        LGKM2(2, kf[0][0], kf[0][1]);
 #pragma unroll
-        for (int df = 0; df < 4; ++df) o[df][g] = mma(vf[df], pf[g], o[df][g]);
-        lacc[g] = mma(ones, pf[g], lacc[g]);
-    };
-    auto grp_sched = [&]() {                                 // 9 MFMAs, 8 transcendentals, 4 packs: M T T M P  x4, M
-        if constexpr (EXP2 && !(ABL & 1)) {
+        for (int qf = 0; qf < QF; ++qf) sn[0][qf] = mma(kf[0][0], qreg[qf][0], negm[qf]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+        for (int qf = 0; qf < QF; ++qf) sn[0][qf] = mma(kf[0][1], qreg[qf][1], sn[0][qf]);
+        exp_pack(sc, 0);
+        if constexpr (EXP2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);   // 2 transcendental
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // 1 VALU (a pack of two earlier exponentials)
+            }
+        }
+        asm volatile("" : "+v"(pf[0]), "+v"(pf[1]));             // the packs are complete here (not sunk to their first use)
+        __builtin_amdgcn_sched_barrier(0);
+        DSRX(vf[0], va, 0 * 2048); DSRX(vf[1], va, 1 * 2048);
+        // ---- A2: second key tile under query tiles 2, 3
+        LGKM2(2, kf[1][0], kf[1][1]);
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) sn[1][qf] = mma(kf[1][0], qreg[qf][0], negm[qf]);
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) sn[1][qf] = mma(kf[1][1], qreg[qf][1], sn[1][qf]);
+        exp_pack(sc, 2);
+        if constexpr (EXP2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
-    };
-    auto step = [&](auto opens_c, f32x4_t (&sc)[2][QF], int hh) {
-        constexpr bool OPENS = decltype(opens_c)::value;
-        const unsigned va = (((hh + 1) & 1) ? vfrag_lane1 : vfrag_lane0) + (unsigned)(((hh + 1) >> 1) % RING) * STAGE_BYTES;
-        const unsigned ka = kfrag_lane + (unsigned)(((hh + 2) >> 1) % RING) * STAGE_BYTES + (unsigned)(hh & 1) * 4096u;
-        // ---- group 0
-        LGKM4(4, kf[0][0], kf[0][1], kf[1][0], kf[1][1]);
-        grp_mma(sc, 0);
-        LGKM4(0, vf[0], vf[1], vf[2], vf[3]);
-        grp_pv(0);
-        exp_pack1(sc, 1);
-        grp_sched();
-        asm volatile("" : "+v"(pf[1]));                          // the packs are complete here (not sunk to their first use)
+        asm volatile("" : "+v"(pf[2]), "+v"(pf[3]));
         __builtin_amdgcn_sched_barrier(0);
-        // ---- group 1
-        grp_mma(sc, 1);
-        grp_pv(1);
-        exp_pack1(sc, 2);
-        grp_sched();
-        asm volatile("" : "+v"(pf[2]));
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- group 2
-        grp_mma(sc, 2);
-        grp_pv(2);
-        exp_pack1(sc, 3);
-        grp_sched();
-        asm volatile("" : "+v"(pf[3]));
-        __builtin_amdgcn_sched_barrier(0);
+        DSRX(vf[2], va, 2 * 2048); DSRX(vf[3], va, 3 * 2048);
         if constexpr (OPENS) enter_tile(std::false_type{}, (hh + 2) >> 1);
-        // ---- group 3: the fragment registers are handed over to the next half-tile as they die
-        grp_mma(sc, 3);
+        // ---- B1: rows 0..31 of O^T and two row-sum tiles under the growth check of the first key tile of S^T(h+1)
+        LGKM2(2, vf[0], vf[1]);
+        pv2(0);
+        int m = (ABL & 16) ? 0 : imax16(sn, 0, (int)0x80000000);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         DSRX(kf[0][0], ka, 0 * 512 + 0 * 64); DSRX(kf[0][1], ka, 0 * 512 + 1 * 64);
-        DSRX(kf[1][0], ka, 1 * 512 + 1 * 64); DSRX(kf[1][1], ka, 1 * 512 + 0 * 64);
-        grp_pv(3);
-        exp_pack1(sc, 0);
-        if constexpr (EXP2 && !(ABL & 1)) {
+        // ---- B2: rows 32..63 under the check of the second key tile
+        LGKM2(2, vf[2], vf[3]);
+        pv2(2);
+        if (!(ABL & 16)) m = imax16(sn, 1, m);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-            }
+        for (int i = 0; i < 8; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
         }
-        asm volatile("" : "+v"(pf[0]));
         __builtin_amdgcn_sched_barrier(0);
-        DSRX(vf[0], va, 0 * 2048); DSRX(vf[1], va, 1 * 2048); DSRX(vf[2], va, 2 * 2048); DSRX(vf[3], va, 3 * 2048);
+        DSRX(kf[1][0], ka, 1 * 512 + 1 * 64); DSRX(kf[1][1], ka, 1 * 512 + 0 * 64);
+        if constexpr (ABL & 16) asm volatile("" :: "v"(m));
+        else if (__builtin_expect(__any(__int_as_float(m) > kDefer), 0)) {
+#ifdef PM_ATTN_COUNT
+            if (lane == 0) atomicAdd(&g_attn_counters[0], 1ull);
+#endif
+            rescale(std::false_type{}, std::false_type{}, sn, hh + 1);
+        }
     };
 
-    // The exact path, one half-tile with every condition at run time, full waits and the running max raised at once: first and
-    // last tiles, ragged tiles, short contexts, and a workgroup the fast path gave up on.  sA: S^T(h) -> P(h) -> S^T(h+1).
+    // The same half-tile with every condition at run time and full waits: first and last tiles, ragged tiles, short contexts.
+    // Always sA -> sB, then sB is copied back.
     auto slow_step = [&](int hh) {
         const bool next = hh + 1 < nhalves, next2 = hh + 2 < nhalves;
-#pragma unroll
-        for (int qf = 0; qf < QF; ++qf) exp_pack1(sA, qf);
-        v_issue(vf, hh);
         if (next) {
-            LGKM4(4, kf[0][0], kf[0][1], kf[1][0], kf[1][1]);
-            qk(sA, kf);
+            LGKM4(0, kf[0][0], kf[0][1], kf[1][0], kf[1][1]);
+            qk(sB, kf);
         }
+        exp_pack(sA, 0);
+        exp_pack(sA, 2);
+        v_issue(vf, hh);
         if (next2 && !(hh & 1)) enter_tile(std::true_type{}, (hh + 2) >> 1);
         if (next2) k_issue(kf, hh + 2);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(kf[0][0]), "+v"(kf[0][1]),
                      "+v"(kf[1][0]), "+v"(kf[1][1]));
         pv2(0);
         pv2(2);
-        if (next) rescale(std::true_type{}, std::false_type{}, sA, hh + 1);
+        if (next) {
+            rescale(std::true_type{}, std::false_type{}, sB, hh + 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int qf = 0; qf < QF; ++qf) sA[kk][qf] = sB[kk][qf];
+        }
     };
 
     constexpr std::true_type Y{};
     constexpr std::false_type N{};
-    __shared__ int redo_vote[4];
 
+    stage_tiles(0);
+    enter_tile(Y, 0);
+    k_issue(kf, 0);
+    LGKM4(0, kf[0][0], kf[0][1], kf[1][0], kf[1][1]);
+    qk(sA, kf);
+    rescale(Y, Y, sA, 0);
+    if (nhalves > 1) k_issue(kf, 1);
+
+    int hs = 0;
     const int nh_full = 2 * (Nkv / KT);                      // half-tiles that lie in full tiles
     // A context without a ragged tile (self-attention: every stage-2 / ViT launch of the decode loop) runs ALL its half-tiles,
-    // the last two included, through the fast step.  Past the end `step` still computes S^T(h+1) and prefetches K(h+2) / V^T(h+1):
-    // they address ring stages that still hold already-consumed tiles (no DMA is issued past the last tile), and nothing they
-    // produce is consumed.
+    // the last two included, through the steady-state step.  Past the end `step` still computes S^T(h+1) and prefetches K(h+2):
+    // both address ring stage ntiles % 3, which still holds tile ntiles - 3 (no DMA is issued past the last tile), i.e. finite
+    // scores of keys that were already folded into the running max, so the growth check cannot fire on them and nothing they
+    // produce is consumed: 16 wasted MFMAs per workgroup-wave instead of two full-wait slow steps with their unconditional
+    // rescale (round 4; the last tile was 6 % of the half-tiles at N = 1024 and ran at less than half the steady-state speed).
     const bool all_steady = (Nkv % KT) == 0 && ntiles >= 3;
     const int steady_end = all_steady ? nhalves - 1 : min(nhalves - 3, nh_full - 2);   // one bound: the loop's shape is unchanged
-    bool exact = steady_end <= 0;                            // workgroup-uniform: no fast step at all, or second attempt
-
-    for (;;) {
-#pragma unroll
-        for (int j = 0; j < QF; ++j) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            lacc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            negm[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-        stage_tiles(0);
-        if (AHEAD == 2 && ntiles > 1) stage_tiles(1);
-        enter_tile(Y, 0);
-        k_issue(kf, 0);
-        LGKM4(0, kf[0][0], kf[0][1], kf[1][0], kf[1][1]);
-        qk(sA, kf);
-        rescale(Y, Y, sA, 0);                                // m_ref = the maximum over the first 32 keys
-        if (nhalves > 1) k_issue(kf, 1);
-
-        int hs = 0;
-        if (!exact) {
-            v_issue(vf, 0);
-            exp_pack1(sA, 0);
-            for (; hs < steady_end; hs += 2) {               // fast path
-                step(Y, sA, hs);
-                step(N, sA, hs + 1);
-            }
-            LGKM4(0, kf[0][0], kf[0][1], kf[1][0], kf[1][1]);    // the reads of the last step are not left outstanding
-            LGKM4(0, vf[0], vf[1], vf[2], vf[3]);
-            // hand-over to the exact steps: sA = S^T(hs) with tiles 1..3 untouched (tile 0 is exponentiated again, same bits), K(hs+1) in kf
-        }
-#ifdef PM_ATTN_COUNT
-        if (lane == 0) { atomicAdd(&g_attn_counters[1], (unsigned long long)hs); atomicAdd(&g_attn_counters[2], (unsigned long long)(nhalves - hs)); }
-#endif
-        for (; hs < nhalves; ++hs) slow_step(hs);
-
-        // every wave is done reading the ring; and the vote: did a probability of the fast path leave the f32 range?
-        bool bad = false;
-        if (!exact && !(ABL & 6)) {                          // (ablations that compute garbage do not vote)
-#pragma unroll
-            for (int qf = 0; qf < QF; ++qf) bad |= !(lacc[qf][0] < 1.8446744e19f);     // 2^64; NaN fails too
-            const int vote = __any(bad) ? 1 : 0;
-            if (lane == 0) redo_vote[wave] = vote;
-        }
-        __syncthreads();
-        if (exact) break;
-        const int4 votes = *reinterpret_cast<const int4*>(redo_vote);
-        if (__builtin_amdgcn_readfirstlane(votes.x | votes.y | votes.z | votes.w) == 0) break;
-        if (tid == 0) atomicAdd(&g_attn_fallbacks, 1ull);
-        exact = true;                                        // (the exact attempt does not vote: no write races the read above)
+    for (; hs < steady_end; hs += 2) {                       // steady state
+        step(Y, sA, sB, hs);
+        step(N, sB, sA, hs + 1);
     }
+#ifdef PM_ATTN_COUNT
+    if (lane == 0) { atomicAdd(&g_attn_counters[1], (unsigned long long)hs); atomicAdd(&g_attn_counters[2], (unsigned long long)(nhalves - hs)); }
+#endif
+    for (; hs < nhalves; ++hs) slow_step(hs);
 
     // ---- finalize: O = O^T / l, head-major inside the output row.  The wave's 64 output rows go through the (now idle)
     // K / V^T ring, so that every global store instruction writes 8 whole 128-byte rows (non-temporal)
     constexpr int RS = 144;                                // staged row: 64 bf16 + pad, 16-B aligned, conflict-free
+    __syncthreads();                                       // every wave is done reading the ring
     unsigned char* obuf = lds + wave * (64 * RS);
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
