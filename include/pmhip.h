@@ -385,6 +385,26 @@ int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const f
                             pmhip_stream stream, float* imgs_host, size_t host_stride,
                             pmhip_stream copy_stream);
 
+/* The same two entry points with GUIDANCE (round 5; an extension behind an explicit argument):
+ * every step runs the tower twice on the step's tokens -- with the context, and as the unconditional branch the reference
+ * trains by dropping the text 10 % of the time (utils/trainer.py:379,387-388: context None, attn2 a second self-attention,
+ * modules/attention.py:47) -- and samples from uncond + guidance_scale * (cond - uncond) (pmhip_guidance_combine); everything
+ * after the logits is the reference's step (generate.py:161-179).  context must not be NULL.  The loop is graph-captured and
+ * lane-able like pmhip_pipeline_generate (one executable graph per guidance_scale value); scale 0 reproduces the unconditional
+ * step bit for bit, and the result equals the operator-level composition pmhip_s2_forward x 2 + pmhip_guidance_combine +
+ * sampling bit for bit (tests/test_gpu_model.py). */
+int pmhip_pipeline_sample_guided(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context, int L,
+                                 int B, int topk, float temperature, int num_mask, const float* noise,
+                                 uint64_t seed, uint32_t step, uint64_t image_base, float* img_out,
+                                 int64_t* pred_out, float* score_out, float guidance_scale,
+                                 pmhip_stream stream);
+int pmhip_pipeline_generate_guided(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context,
+                                   int L, int B, int T, const float* temps_host, const int* nmask_host,
+                                   const unsigned char* decode_host, int topk, uint64_t seed,
+                                   uint64_t image_base, float* imgs_out, int use_graph,
+                                   pmhip_stream stream, float* imgs_host, size_t host_stride,
+                                   pmhip_stream copy_stream, float guidance_scale);
+
 /* Per-kernel timing hook used by bench.py: when enabled, every kernel launch of the named family
  * is bracketed by hipEvents on its own stream and accumulated (count, total ms). */
 int pmhip_timing_enable(int on);

@@ -229,7 +229,6 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
             const float mold = first ? -INFINITY : -negm[qf][0];
             const float mb = first ? 0.f : mold;             // what the accumulators started from
             const float mnew = vmax3(mold, group4_max(m) + mb, -1e30f);   // column max over the 4 lane groups
-            const float alpha = EXP2 ? __builtin_amdgcn_exp2f(mold - mnew) : expf(mold - mnew);
             const float delta = mb - mnew;                   // scores hold s - mb: move them to s - mnew
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -242,10 +241,13 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
             } else {
                 negm[qf][0] += delta; negm[qf][1] += delta; negm[qf][2] += delta; negm[qf][3] += delta;
             }
-            lacc[qf][0] *= alpha; lacc[qf][1] *= alpha; lacc[qf][2] *= alpha; lacc[qf][3] *= alpha;
+            if constexpr (!first) {                          // (the first half-tile finds l = O = 0: nothing to move)
+                const float alpha = EXP2 ? __builtin_amdgcn_exp2f(mold - mnew) : expf(mold - mnew);
+                lacc[qf][0] *= alpha; lacc[qf][1] *= alpha; lacc[qf][2] *= alpha; lacc[qf][3] *= alpha;
 #pragma unroll
-            for (int df = 0; df < 4; ++df) {
-                o[df][qf][0] *= alpha; o[df][qf][1] *= alpha; o[df][qf][2] *= alpha; o[df][qf][3] *= alpha;
+                for (int df = 0; df < 4; ++df) {
+                    o[df][qf][0] *= alpha; o[df][qf][1] *= alpha; o[df][qf][2] *= alpha; o[df][qf][3] *= alpha;
+                }
             }
         }
     };

@@ -3,6 +3,7 @@
 // loop (generate.py:159-198), expressed as sequences of the operator-level launches of this
 // library on one HIP stream.  No host synchronisation happens inside a forward pass.
 #include <stdarg.h>
+#include <string.h>
 
 #include <algorithm>
 #include <atomic>
@@ -720,7 +721,9 @@ int s2_prepare_context(pmhip_s2* h, const float* context, int L, int B, hipStrea
 }
 
 // token rows (T [M,64]) -> logits fp32 [M,V]  (transformer.py:81-82,87-91)
-int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s) {
+// use_cross = false: the unconditional branch (context None: every attn2 is a second self-attention, attention.py:47) although a
+// context has been prepared -- the second forward of a guided step
+int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s, bool use_cross = true) {
     const auto& c = h->cfg;
     const int M = B * c.tokens, dim = c.tower.dim;
     TowerBufs tb;
@@ -729,7 +732,7 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s) {
     PM_TRY(pos_source(h->ws, "pos", tb.hilo, h->w.pos, c.tokens, dim, h->pos_split, pos, s));
     PM_TRY(residual_gemm(h->dtype, tb, tp, 64, h->w.tokproj_w, 64, h->w.tokproj_b, pos, M, dim, 64, s));
     for (int l = 0; l < c.tower.depth; ++l)
-        PM_TRY(layer_forward(h->dtype, h->layers[l], c.tower, tb, B, c.tokens, true, &h->cross[l], s));
+        PM_TRY(layer_forward(h->dtype, h->layers[l], c.tower, tb, B, c.tokens, true, use_cross ? &h->cross[l] : nullptr, s));
     if (tb.fold && h->w.logits_wf && fold_shape_ok(c.tokens, c.n_embed, dim)) {
         PM_TRY(tower_coef(tb, M, dim, s));
         const int step = fold_rows(tb, M, c.tokens, dim);
@@ -746,9 +749,11 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s) {
 }
 
 // Pipeline.sample after the context is prepared (generate.py:161-179)
+// guidance != nullptr: the step's logits are uncond + *guidance * (cond - uncond), uncond = the same tower without the context
+// (the branch the reference trains by dropping the text, utils/trainer.py:379,387-388); everything after the logits is unchanged
 int sample_step(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, int B, int topk, float temperature, int num_mask,
                 const float* noise, uint64_t seed, uint32_t step, uint64_t image_base, float* img_out, int64_t* pred_out,
-                float* score_out, hipStream_t s, const PmGenParams* gp = nullptr) {
+                float* score_out, hipStream_t s, const PmGenParams* gp = nullptr, const float* guidance = nullptr) {
     const auto& c = s2->cfg;
     const int M = B * c.tokens;
     void* tp; float* logits; int64_t* pred; float* score;
@@ -759,6 +764,12 @@ int sample_step(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, int B, int topk, fl
     // ids2tokens: lookup in cat(raw codebook, mask_token) (generate.py:148-157)
     PM_TRY(pmhip_embed_rows(s2->w.tok_table, ids, tp, s2->dtype, 64, M, c.n_embed + 1, c.embed_dim, s));
     PM_TRY(s2_tower(s2, tp, B, logits, s));
+    if (guidance) {
+        float* uncond;
+        WS(s2->ws, "s2.logits_u", (size_t)M * c.n_embed * 4, uncond);
+        PM_TRY(s2_tower(s2, tp, B, uncond, s, false));
+        PM_TRY(pmhip_guidance_combine(logits, uncond, *guidance, logits, (size_t)M * c.n_embed, s));
+    }
     PM_TRY(pm_sample_rows(logits, c.n_embed, ids, (int64_t)c.n_embed, topk, temperature, noise, seed, step,
                           image_base * (uint64_t)c.tokens, pred, ids, score, M, c.n_embed, gp, s));
     if (img_out) {
@@ -795,12 +806,25 @@ extern "C" int pmhip_pipeline_sample(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids
                        score_out, s);
 }
 
-extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context, int L, int B,
-                                       int T, const float* temps_host, const int* nmask_host,
-                                       const unsigned char* decode_host, int topk, uint64_t seed, uint64_t image_base,
-                                       float* imgs_out, int use_graph, pmhip_stream stream, float* imgs_host,
-                                       size_t host_stride, pmhip_stream copy_stream) {
+extern "C" int pmhip_pipeline_sample_guided(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context, int L, int B,
+                                            int topk, float temperature, int num_mask, const float* noise, uint64_t seed,
+                                            uint32_t step, uint64_t image_base, float* img_out, int64_t* pred_out,
+                                            float* score_out, float guidance_scale, pmhip_stream stream) {
+    PM_REQUIRE(s2 && ids && B > 0, "pipeline_sample_guided: bad arguments");
+    PM_REQUIRE(context && L > 0, "pipeline_sample_guided: guidance needs a context (context NULL IS the unconditional branch)");
+    hipStream_t s = (hipStream_t)stream;
+    PM_TRY(s2_prepare_context(s2, context, L, B, s));
+    return sample_step(s2, vq, ids, B, topk, temperature, num_mask, noise, seed, step, image_base, img_out, pred_out,
+                       score_out, s, nullptr, &guidance_scale);
+}
+
+static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context, int L, int B,
+                             int T, const float* temps_host, const int* nmask_host,
+                             const unsigned char* decode_host, int topk, uint64_t seed, uint64_t image_base,
+                             float* imgs_out, int use_graph, pmhip_stream stream, float* imgs_host,
+                             size_t host_stride, pmhip_stream copy_stream, const float* guidance) {
     PM_REQUIRE(s2 && ids && B > 0 && T > 0 && temps_host && nmask_host, "pipeline_generate: bad arguments");
+    PM_REQUIRE(!guidance || (context && L > 0), "pipeline_generate_guided: guidance needs a context (context NULL IS the unconditional branch)");
     hipStream_t s = (hipStream_t)stream;
     hipStream_t cs = copy_stream ? (hipStream_t)copy_stream : s;
     PM_TRY(s2_prepare_context(s2, context, L, B, s));         // context projection + cross K/V: once per loop, eager
@@ -868,7 +892,7 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
             const bool dec = decode_host && decode_host[t];
             float* img = !dec ? nullptr : (gimgs ? gimgs : imgs_out) + (size_t)d * img_elems;
             PM_TRY(sample_step(s2, vq, ids, B, topk, temps_host[t], nmask_host[t], nullptr, seed, (uint32_t)t, image_base, img,
-                               nullptr, nullptr, s));
+                               nullptr, nullptr, s, nullptr, guidance));
             PM_TRY(flush_pending());                           // the previous image, now that one more step is queued behind it
             if (dec) PM_TRY(deliver(d++, img));
         }
@@ -900,7 +924,13 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
 
     std::string key = "B" + std::to_string(B) + "T" + std::to_string(T) + "k" + std::to_string(topk) + "L" +
                       std::to_string(context ? L : 0) + "v" + std::to_string(vq ? vq->uid : 0) + "f" +
-                      std::to_string(s2->sw.key() * 16 + (vq ? vq->sw.key() : 0)) + "d";
+                      std::to_string(s2->sw.key() * 16 + (vq ? vq->sw.key() : 0));
+    if (guidance) {                                           // the scale is a kernel argument of the captured combine: one graph per value
+        unsigned bits;
+        memcpy(&bits, guidance, 4);
+        key += "g" + std::to_string(bits);
+    }
+    key += "d";
     for (int t = 0; t < T; ++t) key += (decode_host && decode_host[t]) ? '1' : '0';
     GraphEntry& ge = s2->graphs[key];
 
@@ -913,7 +943,7 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
         int d = d0;
         for (int t = t0; t < t1; ++t) {
             float* img = (decode_host && decode_host[t]) ? gimgs + (size_t)(d++) * img_elems : nullptr;
-            PM_TRY(sample_step(s2, vq, gids, B, topk, 0.f, 0, nullptr, 0, (uint32_t)t, 0, img, nullptr, nullptr, on, gparams));
+            PM_TRY(sample_step(s2, vq, gids, B, topk, 0.f, 0, nullptr, 0, (uint32_t)t, 0, img, nullptr, nullptr, on, gparams, guidance));
         }
         return PMHIP_OK;
     };
@@ -973,4 +1003,22 @@ extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* i
     }
     PM_HIP(hipMemcpyAsync(ids, gids, ids_bytes, hipMemcpyDeviceToDevice, s));
     return flush_pending();
+}
+
+extern "C" int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context, int L, int B,
+                                       int T, const float* temps_host, const int* nmask_host,
+                                       const unsigned char* decode_host, int topk, uint64_t seed, uint64_t image_base,
+                                       float* imgs_out, int use_graph, pmhip_stream stream, float* imgs_host,
+                                       size_t host_stride, pmhip_stream copy_stream) {
+    return pipeline_generate(s2, vq, ids, context, L, B, T, temps_host, nmask_host, decode_host, topk, seed, image_base, imgs_out,
+                             use_graph, stream, imgs_host, host_stride, copy_stream, nullptr);
+}
+
+extern "C" int pmhip_pipeline_generate_guided(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context, int L, int B,
+                                              int T, const float* temps_host, const int* nmask_host,
+                                              const unsigned char* decode_host, int topk, uint64_t seed, uint64_t image_base,
+                                              float* imgs_out, int use_graph, pmhip_stream stream, float* imgs_host,
+                                              size_t host_stride, pmhip_stream copy_stream, float guidance_scale) {
+    return pipeline_generate(s2, vq, ids, context, L, B, T, temps_host, nmask_host, decode_host, topk, seed, image_base, imgs_out,
+                             use_graph, stream, imgs_host, host_stride, copy_stream, &guidance_scale);
 }

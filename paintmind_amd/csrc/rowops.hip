@@ -187,8 +187,8 @@ __global__ __launch_bounds__(THREADS) void add_rows_kernel(const float* __restri
 // out = uncond + scale * (cond - uncond): logits of a text-conditioned and an unconditional forward combined for guidance
 // (the reference TRAINS for this -- 10 % text drop, utils/trainer.py:379,387-388 -- but its inference never combines them; an
 // extension behind an explicit keyword).  One fused multiply-add per element in fp32, in place when out aliases cond or uncond.
-__global__ __launch_bounds__(THREADS) void guidance_kernel(const float* __restrict__ cond, const float* __restrict__ uncond, float scale,
-                                                           float* __restrict__ out, size_t n4) {
+// (no __restrict__: out is documented to alias cond or uncond; every element is read and then written by the same lane)
+__global__ __launch_bounds__(THREADS) void guidance_kernel(const float* cond, const float* uncond, float scale, float* out, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * THREADS) {
         const float4 c = reinterpret_cast<const float4*>(cond)[i], u = reinterpret_cast<const float4*>(uncond)[i];
         reinterpret_cast<float4*>(out)[i] = make_float4(fmaf(scale, c.x - u.x, u.x), fmaf(scale, c.y - u.y, u.y), fmaf(scale, c.z - u.z, u.z),

@@ -277,8 +277,9 @@ class S2Engine:
         return logits
 
     def sample(self, vq_engine, ids, context, topk, temperature, num_mask, noise=None, seed=0, step=0, image_base=0,
-               want_img=True, want_aux=False):
-        """one MaskGIT step; ids int64 [B,N] is updated IN PLACE (pass a clone to keep the input)."""
+               want_img=True, want_aux=False, guidance_scale=None):
+        """one MaskGIT step; ids int64 [B,N] is updated IN PLACE (pass a clone to keep the input).
+        guidance_scale (None = the reference's step): sample from uncond + scale * (cond - uncond), two tower passes."""
         B = ids.shape[0]
         context, L = self._ctx(context)
         img = vq_engine._new_img(B) if want_img else None
@@ -286,15 +287,19 @@ class S2Engine:
         score = torch.empty(B, self.tokens, device=self.device, dtype=torch.float32) if want_aux else None
         if noise is not None:
             noise = noise.to(self.device, torch.float32).contiguous()
-        with torch.cuda.device(self.device):
-            check(self.lib.pmhip_pipeline_sample(
-                self.handle, vq_engine.handle if vq_engine is not None else C.c_void_p(0), _p(ids), _p(context), L, B,
+        args = (self.handle, vq_engine.handle if vq_engine is not None else C.c_void_p(0), _p(ids), _p(context), L, B,
                 int(topk), float(temperature), int(num_mask), _p(noise), int(seed), int(step), int(image_base), _p(img),
-                _p(pred), _p(score), stream_ptr(self.device)), "pmhip_pipeline_sample")
+                _p(pred), _p(score))
+        with torch.cuda.device(self.device):
+            if guidance_scale is None:
+                check(self.lib.pmhip_pipeline_sample(*args, stream_ptr(self.device)), "pmhip_pipeline_sample")
+            else:
+                check(self.lib.pmhip_pipeline_sample_guided(*args, float(guidance_scale), stream_ptr(self.device)),
+                      "pmhip_pipeline_sample_guided")
         return ids, img, pred, score
 
     def generate(self, vq_engine, ids, context, temps, nmask, decode_flags, topk, seed=0, image_base=0, use_graph=False,
-                 host=None, want_device_imgs=True):
+                 host=None, want_device_imgs=True, guidance_scale=None):
         """T MaskGIT steps in one native call; returns imgs [n_decoded, B, C, H, W] (device) or None.
 
         host = (pinned float32 tensor [n_decoded, B_total, C, H, W], first row of this batch, copy stream): every decoded
@@ -320,9 +325,12 @@ class S2Engine:
         temps_c = (C.c_float * T)(*[float(t) for t in temps])
         nmask_c = (C.c_int * T)(*[int(n) for n in nmask])
         dec_c = (C.c_ubyte * T)(*[1 if f else 0 for f in decode_flags])
-        with torch.cuda.device(self.device):
-            check(self.lib.pmhip_pipeline_generate(
-                self.handle, vq_engine.handle if vq_engine is not None else C.c_void_p(0), _p(ids), _p(context), L, B, T,
+        args = (self.handle, vq_engine.handle if vq_engine is not None else C.c_void_p(0), _p(ids), _p(context), L, B, T,
                 temps_c, nmask_c, dec_c, int(topk), int(seed), int(image_base), _p(imgs), int(use_graph),
-                stream_ptr(self.device), host_ptr, host_stride, copy_stream), "pmhip_pipeline_generate")
+                stream_ptr(self.device), host_ptr, host_stride, copy_stream)
+        with torch.cuda.device(self.device):
+            if guidance_scale is None:
+                check(self.lib.pmhip_pipeline_generate(*args), "pmhip_pipeline_generate")
+            else:
+                check(self.lib.pmhip_pipeline_generate_guided(*args, float(guidance_scale)), "pmhip_pipeline_generate_guided")
         return ids, imgs

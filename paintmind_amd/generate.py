@@ -252,15 +252,16 @@ class Pipeline(nn.Module):
             seed = _draw_seed()
         eng = self.engine()
         ids = ids.to(eng.device, torch.int64).clone().contiguous()
-        if guidance_scale is not None:
-            return self._sample_guided(eng, ids, nm, text, topk, temperature, noise, seed, step, image_base, guidance_scale)
         ids, img, _, _ = eng.sample(self.vqgan.engine(), ids, text, topk, temperature, nm, noise=noise, seed=seed, step=step,
-                                    image_base=image_base, want_img=True)
+                                    image_base=image_base, want_img=True, guidance_scale=guidance_scale)
         return ids, img
 
-    def _sample_guided(self, eng, ids, nm, text, topk, temperature, noise, seed, step, image_base, scale):
+    def _sample_guided_composed(self, ids, nm, text, topk, temperature, noise, seed, step, image_base, scale):
         """the guided step composed from the operator-level C ABI (two pmhip_s2_forward + pmhip_guidance_combine +
-        pmhip_sample_rows + decode + pmhip_remask): the same kernels, in the same order, as pmhip_pipeline_sample"""
+        pmhip_sample_rows + decode + pmhip_remask): the same kernels, in the same order, as pmhip_pipeline_sample_guided.
+        Not on any product path: the bit-identity reference of tests/test_gpu_model.py for the native guided step / loop."""
+        eng = self.engine()
+        ids = ids.to(eng.device, torch.int64).clone().contiguous()
         B, N = ids.shape
         tok = self.ids2tokens(ids)
         cond = eng.forward(tok, text)
@@ -338,7 +339,7 @@ class Pipeline(nn.Module):
         return torch.cuda.Stream(device=device)
 
     def generate_ids(self, context, B, timesteps, temperature, topk, decode_flags, seed, image_base=0, use_graph=False, streams=1,
-                     join=True, wait_current=True, host=None):
+                     join=True, wait_current=True, host=None, guidance_scale=None):
         """The decode loop on device tensors: returns (ids [B,N], imgs [n_decoded,B,C,H,W] or None).
 
         streams > 1 (or a tuple of micro-batch sizes): the batch is cut into contiguous micro-batches that run CONCURRENTLY on separate HIP
@@ -370,7 +371,8 @@ class Pipeline(nn.Module):
             ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
             return eng.generate(self.vqgan.engine(), ids, context, temps, nmask, decode_flags, topk, seed=seed,
                                 image_base=image_base, use_graph=use_graph,
-                                host=None if host is None else (host[0], 0, host[1][0]), want_device_imgs=host is None)
+                                host=None if host is None else (host[0], 0, host[1][0]), want_device_imgs=host is None,
+                                guidance_scale=guidance_scale)
         from .dist import shard_range
         cur = torch.cuda.current_stream(eng.device)
         if wait_current:
@@ -386,7 +388,7 @@ class Pipeline(nn.Module):
                 c = None if context is None else context[lo:hi].contiguous()
                 ids, imgs = e.generate(v, ids, c, temps, nmask, decode_flags, topk, seed=seed, image_base=image_base + lo,
                                        use_graph=use_graph, host=None if host is None else (host[0], lo, host[1][i]),
-                                       want_device_imgs=host is None)
+                                       want_device_imgs=host is None, guidance_scale=guidance_scale)
             return ids, imgs, st
 
         lanes = self._lanes(streams)
@@ -443,10 +445,11 @@ class Pipeline(nn.Module):
         the list is dropped.  `.clone()` a result to own ordinary pageable memory, as the reference's `img.cpu()` returns."""
         B = len(text)
         context = self.text_model(text)
-        if guidance_scale is not None:
-            return self._generate_guided(context, B, timesteps, temperature, topk, save_interval, seed, image_base, return_ids,
-                                         keep_on_device, guidance_scale)
+        if guidance_scale is not None and context is None:
+            raise ValueError("guidance_scale needs a text condition (text=None IS the unconditional branch)")
         if self._on_cpu():
+            if guidance_scale is not None:
+                return self._generate_guided_cpu(context, B, timesteps, temperature, topk, save_interval, seed, return_ids, guidance_scale)
             return self._generate_cpu(text, context, timesteps, temperature, topk, save_interval, seed, return_ids)
         eng = self.engine()
         if seed is None:
@@ -464,7 +467,7 @@ class Pipeline(nn.Module):
         n_dec = sum(flags)
         if keep_on_device or n_dec == 0:
             ids, imgs = self.generate_ids(context, B, timesteps, temperature, topk, flags, seed, image_base=image_base,
-                                          use_graph=use_graph, streams=streams)
+                                          use_graph=use_graph, streams=streams, guidance_scale=guidance_scale)
             out = [] if imgs is None else list(imgs)
             return (out, ids) if return_ids else out
         vq = self.vqgan.engine()
@@ -478,7 +481,7 @@ class Pipeline(nn.Module):
             cs.append(torch.cuda.Stream(device=eng.device))
         try:
             ids, _ = self.generate_ids(context, B, timesteps, temperature, topk, flags, seed, image_base=image_base,
-                                       use_graph=use_graph, streams=streams, host=(host, cs))
+                                       use_graph=use_graph, streams=streams, host=(host, cs), guidance_scale=guidance_scale)
         except BaseException:
             # a lane failed: whatever the other lanes queued may still be writing into `host`; drain it, and never hand
             # this buffer out again
@@ -498,23 +501,17 @@ class Pipeline(nn.Module):
         return (out, ids) if return_ids else out
 
     @torch.no_grad()
-    def _generate_guided(self, context, B, timesteps, temperature, topk, save_interval, seed, image_base, return_ids, keep_on_device,
-                         scale):
-        """generate.py:183-198 with guided steps (see `sample`): an eager loop of two forwards per step; same return structure"""
-        if context is None:
-            raise ValueError("guidance_scale needs a text condition")
-        if seed is None:
-            seed = _draw_seed()
-        dev = self.mask_token.device
-        ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=dev)
-        context = context.to(dev)
+    def _generate_guided_cpu(self, context, B, timesteps, temperature, topk, save_interval, seed, return_ids, scale):
+        """generate.py:183-198 with guided steps (see `sample`) for a pipeline that lives on the CPU; same return structure.
+        (On the GPU the guided loop is the native one: pmhip_pipeline_generate_guided, graph-captured and lane-able.)"""
+        ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long)
         imgs = []
         for step in range(timesteps):
-            ids, img = self.sample(ids, mask_schedule((step + 1) / timesteps), text=context, topk=topk,
-                                   temperature=temperature * (1 - step / timesteps), seed=seed if not self._on_cpu() else seed + step,
-                                   step=step, image_base=image_base, guidance_scale=scale)
+            nm = num_token_masked(mask_schedule((step + 1) / timesteps), self.num_tokens)
+            ids, img = self._sample_cpu(ids, nm, context, topk, temperature * (1 - step / timesteps), None,
+                                        None if seed is None else seed + step, scale)
             if step % save_interval == 0:
-                imgs.append(img if keep_on_device else img.cpu())
+                imgs.append(img)
         return (imgs, ids) if return_ids else imgs
 
     def _region_loop(self, img, coord, text, timesteps, topk, temperature, keep_inside, seed=None, return_ids=False):

@@ -371,7 +371,13 @@ def guidance_combine(cond, uncond, scale, out=None):
     dev = _dev(cond, uncond)
     if cond.shape != uncond.shape or cond.dtype != torch.float32 or uncond.dtype != torch.float32:
         raise ValueError("guidance_combine needs two fp32 tensors of one shape")
-    out = torch.empty_like(cond) if out is None else out
+    out = torch.empty(cond.shape, device=dev, dtype=torch.float32) if out is None else out
+    if out.shape != cond.shape or out.dtype != torch.float32 or out.device != cond.device:
+        raise ValueError("guidance_combine: `out` must be an fp32 tensor of the inputs' shape on their device")
+    if not (cond.is_contiguous() and uncond.is_contiguous() and out.is_contiguous()):
+        raise ValueError("guidance_combine needs contiguous tensors (the kernel walks them as flat arrays)")
+    if cond.numel() % 4:
+        raise ValueError("guidance_combine: the element count must be a multiple of 4")
     with torch.cuda.device(dev):
         check(_lib.load().pmhip_guidance_combine(_p(cond), _p(uncond), float(scale), _p(out), cond.numel(), stream_ptr(dev)),
               "pmhip_guidance_combine")

@@ -122,6 +122,46 @@ def test_guided_sample_step_against_oracle(tiny_pipe, scale):
     assert int((ids == 64).sum(1).max()) == 1
 
 
+def test_guided_native_loop_is_bit_identical_to_the_operator_composition(tiny_pipe):
+    """Round 5: the guided step / loop run natively (pmhip_pipeline_sample_guided, pmhip_pipeline_generate_guided: both towers,
+    the combine and the reference's tail inside the graph-captured, lane-able loop).  Its reference is the operator-level
+    composition of the SAME C-ABI pieces (pmhip_s2_forward x 2, pmhip_guidance_combine, pmhip_sample_rows, decode,
+    pmhip_remask) step by step in Python -- which test_guided_sample_step_against_oracle ties to the oracle: ids and every
+    saved image bit-identical, in both precision modes, eager / graph capture / replay / two lanes."""
+    from paintmind_amd.generate import mask_schedule, num_token_masked
+    pipe, p, d = tiny_pipe
+    texts = [f"t{i}" for i in range(9)]
+    T, scale, topk, seed = 5, 2.5, 4, 77
+    try:
+        for dtype in (torch.float32, torch.bfloat16):
+            pipe.set_compute_dtype(dtype)
+            ctx = pipe.text_model(texts).to(dev())
+            ids = torch.full((len(texts), pipe.num_tokens), pipe.mask_token_id, dtype=torch.long, device=dev())
+            ref = []
+            for step in range(T):
+                nm = num_token_masked(mask_schedule((step + 1) / T), pipe.num_tokens)
+                temp = 1.0 * (1 - step / T)
+                one_ids, one_img = pipe.sample(ids, mask_schedule((step + 1) / T), text=ctx, topk=topk, temperature=temp, seed=seed,
+                                               step=step, guidance_scale=scale)
+                ids, img = pipe._sample_guided_composed(ids, nm, ctx, topk, temp, None, seed, step, 0, scale)
+                assert torch.equal(one_ids, ids) and torch.equal(one_img, img), (dtype, step)      # the native guided STEP
+                ref.append(img.cpu())
+            kw = dict(timesteps=T, topk=topk, save_interval=1, seed=seed, guidance_scale=scale, return_ids=True)
+            for mode in (dict(use_graph=False, streams=1), dict(), dict(), dict(), dict(use_graph=True, streams=2), dict(use_graph=True, streams=2),
+                         dict(use_graph=True, streams=2)):
+                imgs, gids = pipe.generate(texts, **kw, **mode)                                     # the native guided LOOP
+                assert torch.equal(gids.cpu(), ids.cpu()), (dtype, mode)
+                assert len(imgs) == T and all(torch.equal(a, b) for a, b in zip(imgs, ref)), (dtype, mode)
+            # another scale is another graph, and scale 0 is the unconditional loop
+            z0 = pipe.generate(texts, **{**kw, "guidance_scale": 0.0})
+            z1 = pipe.generate(texts, **{**kw, "guidance_scale": 0.0})
+            un = pipe.generate_ids(None, len(texts), T, 1.0, topk, [True] * T, seed, use_graph=False, streams=1)
+            assert torch.equal(z0[1].cpu(), z1[1].cpu()) and torch.equal(z0[1].cpu(), un[0].cpu())
+            assert all(torch.equal(a, b.cpu()) for a, b in zip(z1[0], un[1]))
+    finally:
+        pipe.set_compute_dtype(torch.float32)
+
+
 def test_tiny_pipeline_decode_loop_golden(tiny_pipe):
     pipe, p, d = tiny_pipe
     ctx = t(d["context"])
