@@ -126,6 +126,11 @@ typedef struct pmhip_lnfold {
     const float* coef;    /* [M][2]: (rstd, -rstd * mean) per row, from pmhip_ln_coef */
     const float* c;       /* [N]: sum_k of the (rounded) gamma-scaled weight row */
     const float* d;       /* [N]: sum_k beta[k] * W[n,k] */
+    /* ABI 9, optional (parts NULL: coef is an input, as before).  parts = the [M][nparts][2] partial statistics
+     * pmhip_gemm_hilo_stats left behind for this hi plane (nparts * 64 = K), eps the LayerNorm's: coef is then an OUTPUT of the
+     * call as well -- written by the GEMM itself where a small launch computes its rows' coefficients in its prologue, by
+     * pmhip_ln_coef_parts (launched by the call) otherwise; bit-identical either way. */
+    const float* parts; int nparts; float eps;
 } pmhip_lnfold;
 
 /* Consumers: same arguments as pmhip_gemm (no residual) / pmhip_gemm_swiglu / pmhip_gemm_heads, with A = the hi plane,
@@ -404,6 +409,14 @@ int pmhip_pipeline_generate_guided(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, 
                                    uint64_t image_base, float* imgs_out, int use_graph,
                                    pmhip_stream stream, float* imgs_host, size_t host_stride,
                                    pmhip_stream copy_stream, float guidance_scale);
+
+/* The PMHIP_* development switches are read from the environment when a handle is CREATED and stay with it (its workspace,
+ * fold decisions and captured graphs depend on them); editing the environment of a live handle does nothing.  These return
+ * what a handle latched: bit 0 LayerNorm fold (PMHIP_LN_UNFOLD unset), bit 1 bf16 hi/lo stream (PMHIP_HILO != 0), bit 2 row
+ * statistics from the producers (PMHIP_LN_STATS != 0), bit 3 centred hi plane (PMHIP_HILO_CENTER != 0), bit 4
+ * PMHIP_BLOCKING_WAIT; -1 for a NULL handle.  A tool that A/Bs a switch asserts the mode it believes it measures. */
+int pmhip_s2_switches(const pmhip_s2* h);
+int pmhip_vqgan_switches(const pmhip_vqgan* h);
 
 /* Per-kernel timing hook used by bench.py: when enabled, every kernel launch of the named family
  * is bracketed by hipEvents on its own stream and accumulated (count, total ms). */

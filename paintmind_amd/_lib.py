@@ -61,7 +61,7 @@ class S2Weights(C.Structure):
 
 class LnFold(C.Structure):
     """mirror of pmhip_lnfold"""
-    _fields_ = [("coef", vp), ("c", vp), ("d", vp)]
+    _fields_ = [("coef", vp), ("c", vp), ("d", vp), ("parts", vp), ("nparts", i32), ("eps", f32)]
 
 
 # name -> (restype, argtypes); every symbol include/pmhip.h declares
@@ -123,6 +123,8 @@ PROTOTYPES = {
     "pmhip_pipeline_sample_guided": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, u64, u32, u64, vp, vp, vp, f32, vp]),
     "pmhip_pipeline_generate_guided": (i32, [vp, vp, vp, vp, i32, i32, i32, C.POINTER(f32), C.POINTER(i32),
                                              C.POINTER(C.c_ubyte), i32, u64, u64, vp, i32, vp, vp, C.c_size_t, vp, f32]),
+    "pmhip_s2_switches": (i32, [vp]),
+    "pmhip_vqgan_switches": (i32, [vp]),
     "pmhip_timing_enable": (i32, [i32]),
     "pmhip_timing_reset": (i32, []),
     "pmhip_timing_get": (i32, [C.c_char_p, C.POINTER(i32), C.POINTER(C.c_double)]),

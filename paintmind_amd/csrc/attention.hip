@@ -498,8 +498,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
 
 // A/B switch while the third-generation bf16 kernel (attention_bf16.hip) is being measured: PMHIP_ATTN_OLD=1
 bool old_bf16_kernel() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PMHIP_ATTN_OLD"); v = e ? atoi(e) : 0; }
+    static const int v = [] { const char* e = getenv("PMHIP_ATTN_OLD"); return e ? atoi(e) : 0; }();   // read once, thread-safe
     return v != 0;
 }
 

@@ -244,5 +244,46 @@ __device__ __forceinline__ float group4_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// LayerNorm fold: per-row (rstd, -rstd * mean) from the partial statistics a hi/lo producer left behind (per 64-column part:
+// sum, and sum of squares centred on the part's own mean).  ONE definition of the arithmetic -- explicitly rounded operations
+// in a fixed tree -- shared by pmhip_ln_coef_parts' kernel (8 lanes per row, DPP sums) and by the folded small-batch GEMM that
+// computes the coefficients of its own rows in its prologue (one lane per row): both produce the same bits, so whether the
+// separate kernel runs may depend on the batch size although an image's result may not.
+//   part j of a row is paired with part j + 8 (missing parts count as zero); the eight pair values are summed as
+//   ((0+1)+(2+3)) + ((4+5)+(6+7))
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lnp_m2_term(float2 part, float mean) {        // centred sum of squares of one part about the ROW mean
+    const float d = __fsub_rn(__fmul_rn(part.x, 1.0f / 64.0f), mean);
+    return __fmaf_rn(__fmul_rn(64.0f, d), d, part.y);
+}
+__device__ __forceinline__ float lnp_mean(float total, int nparts) { return __fdiv_rn(total, (float)(nparts * 64)); }
+__device__ __forceinline__ float2 lnp_finish(float m2, float mean, int nparts, float eps) {
+    const float rstd = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fdiv_rn(m2, (float)(nparts * 64)), eps)));
+    return make_float2(rstd, __fmul_rn(-rstd, mean));
+}
+__device__ __forceinline__ float lnp_tree8(const float (&v)[8]) {
+    return __fadd_rn(__fadd_rn(__fadd_rn(v[0], v[1]), __fadd_rn(v[2], v[3])), __fadd_rn(__fadd_rn(v[4], v[5]), __fadd_rn(v[6], v[7])));
+}
+// one lane, one row: pr = the row's nparts (sum, centred sum of squares) pairs, nparts <= 16.  Load and arithmetic are separate
+// so that a caller can request the pairs early and combine them late.
+__device__ __forceinline__ void ln_coef_row_load(const float2* pr, int nparts, float2 (&pa)[8], float2 (&pb)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        pa[j] = j < nparts ? pr[j] : make_float2(0.f, 0.f);
+        pb[j] = j + 8 < nparts ? pr[j + 8] : make_float2(0.f, 0.f);
+    }
+}
+__device__ __forceinline__ float2 ln_coef_row(const float2 (&pa)[8], const float2 (&pb)[8], int nparts, float eps) {
+    float sv[8], mv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sv[j] = __fadd_rn(pa[j].x, pb[j].x);
+    const float mean = lnp_mean(lnp_tree8(sv), nparts);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        mv[j] = __fadd_rn(j < nparts ? lnp_m2_term(pa[j], mean) : 0.f, j + 8 < nparts ? lnp_m2_term(pb[j], mean) : 0.f);
+    return lnp_finish(lnp_tree8(mv), mean, nparts, eps);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t dtype_size(int dtype) { return dtype == PMHIP_BF16 ? 2 : 4; }

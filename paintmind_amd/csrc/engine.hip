@@ -299,11 +299,20 @@ int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W
     return pmhip_gemm(dtype, A, lda, W, ldw, bias, r.f32, r.ld, r.rows, b.x, N, PMHIP_F32, M, N, K, s);
 }
 
-// (rstd, -rstd * mean) of the rows of the current hi plane into b.coef
+// (rstd, -rstd * mean) of the rows of the current hi plane into b.coef.  Where the last residual GEMM left partial row statistics
+// behind, the folded consumer itself produces coef from them (pmhip_lnfold::parts: in its own prologue for a small launch, by
+// pmhip_ln_coef_parts in front of it otherwise) and nothing is launched here; else the pass over the plane.
 int tower_coef(TowerBufs& b, int M, int dim, hipStream_t s) {
     b.coef_valid = true;
-    if (b.parts_valid) return pmhip_ln_coef_parts(b.parts, dim / 64, 1e-5f, b.coef, M, s);
+    if (b.parts_valid) return PMHIP_OK;
     return pmhip_ln_coef(b.xh, 1e-5f, b.coef, M, dim, s);
+}
+// the fold descriptor of the rows [m0, ...) of the tower
+pmhip_lnfold fold_desc(const TowerBufs& b, int m0, int dim, const float* c, const float* d) {
+    pmhip_lnfold ln{};
+    ln.coef = b.coef + (size_t)m0 * 2; ln.c = c; ln.d = d;
+    if (b.parts_valid) { ln.parts = b.parts + (size_t)m0 * (dim / 64) * 2; ln.nparts = dim / 64; ln.eps = 1e-5f; }
+    return ln;
 }
 
 // LN(x) of the tower's residual stream into b.y (the unfolded path)
@@ -345,7 +354,7 @@ int ln_heads(int dtype, TowerBufs& b, const float* g, const float* be, const voi
             void* o[3] = {nullptr, nullptr, nullptr};
             for (int i = 0; i < nparts; ++i)
                 o[i] = reinterpret_cast<unsigned char*>(outs[i]) + b0 * heads * (kinds[i] == PMHIP_PART_Q ? tokens : Np) * 64 * dtype_size(dtype);
-            const pmhip_lnfold ln{b.coef + (size_t)m0 * 2, fc, fd};
+            const pmhip_lnfold ln = fold_desc(b, m0, dim, fc, fd);
             PM_TRY(pmhip_gemm_heads_ln(dtype, reinterpret_cast<const unsigned char*>(b.xh) + (size_t)m0 * dim * 2, dim, Wf, dim, rows, dim, heads,
                                        tokens, Np, nparts, kinds, o, q_scale, &ln, s));
         }
@@ -396,7 +405,7 @@ int layer_forward(int dtype, const pmhip_layer_weights& L, const pmhip_tower_cfg
         PM_TRY(tower_coef(b, M, dim, s));
         const int step = fold_rows(b, M, tokens, dim);
         for (int m0 = 0; m0 < M; m0 += step) {
-            const pmhip_lnfold ln{b.coef + (size_t)m0 * 2, L.w12_c, L.w12_d};
+            const pmhip_lnfold ln = fold_desc(b, m0, dim, L.w12_c, L.w12_d);
             PM_TRY(pmhip_gemm_swiglu_ln(dtype, reinterpret_cast<const unsigned char*>(b.xh) + (size_t)m0 * dim * 2, dim, L.w12p_f, L.b12p,
                                         reinterpret_cast<unsigned char*>(b.hid) + (size_t)m0 * tc.hidden_pad * dtype_size(dtype), tc.hidden_pad,
                                         std::min(step, M - m0), tc.hidden_pad, dim, &ln, s));
@@ -431,9 +440,9 @@ int pos_source(Workspace& ws, const char* tag, bool hilo, const float* pos, int 
 // ------------------------------------------------------------------------------------------------
 // VQModel
 // ------------------------------------------------------------------------------------------------
-static uint64_t g_next_vq_uid = 1;
+static std::atomic<uint64_t> g_next_vq_uid{1};   // handles are created from lane threads too (Pipeline._lanes clones)
 struct pmhip_vqgan {
-    uint64_t uid = g_next_vq_uid++;     // graph keys name the handle by this, never by its (reusable) heap address
+    uint64_t uid = g_next_vq_uid.fetch_add(1, std::memory_order_relaxed);   // graph keys name the handle by this, never by its (reusable) heap address
     int device = 0, dtype = 0;
     pmhip_vqgan_cfg cfg{};
     pmhip_vqgan_weights w{};
@@ -737,7 +746,7 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s, b
         PM_TRY(tower_coef(tb, M, dim, s));
         const int step = fold_rows(tb, M, c.tokens, dim);
         for (int m0 = 0; m0 < M; m0 += step) {
-            const pmhip_lnfold ln{tb.coef + (size_t)m0 * 2, h->w.logits_c, h->w.logits_d};   // the final norm folded into to_logits
+            const pmhip_lnfold ln = fold_desc(tb, m0, dim, h->w.logits_c, h->w.logits_d);   // the final norm folded into to_logits
             PM_TRY(pmhip_gemm_ln(h->dtype, reinterpret_cast<const unsigned char*>(tb.xh) + (size_t)m0 * dim * 2, dim, h->w.logits_wf, dim,
                                  h->w.logits_b, logits + (size_t)m0 * c.n_embed, c.n_embed, PMHIP_F32, std::min(step, M - m0), c.n_embed, dim, &ln, s));
         }
@@ -1022,3 +1031,7 @@ extern "C" int pmhip_pipeline_generate_guided(pmhip_s2* s2, pmhip_vqgan* vq, int
     return pipeline_generate(s2, vq, ids, context, L, B, T, temps_host, nmask_host, decode_host, topk, seed, image_base, imgs_out,
                              use_graph, stream, imgs_host, host_stride, copy_stream, &guidance_scale);
 }
+
+// the PMHIP_* switches a handle latched when it was created (bit 0 fold, 1 hilo, 2 stats, 3 center, 4 blocking_wait)
+extern "C" int pmhip_s2_switches(const pmhip_s2* h) { return h ? h->sw.key() + (h->sw.blocking_wait ? 16 : 0) : -1; }
+extern "C" int pmhip_vqgan_switches(const pmhip_vqgan* h) { return h ? h->sw.key() + (h->sw.blocking_wait ? 16 : 0) : -1; }

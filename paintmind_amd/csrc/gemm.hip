@@ -48,9 +48,20 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ base, int ld, i
     }
 }
 
-template <typename T, int EPI, typename OutT>
+// FOLD (bf16 only): the LayerNorm folded into this GEMM, as in the 256x256 kernel (gemm_common.h: A is the raw hi plane, W carries
+// gamma, the epilogue applies rstd * acc - rstd * mean * c[n] + d[n]).  Same MFMA chain per output element (K-tiles in order, the
+// two k-halves of a K-tile in order), same ln_apply4 arithmetic: the result is BIT-IDENTICAL to the 256x256 kernel's
+// (tests/test_gpu_ops.py), so which of the two serves a shape may depend on the batch size although an image's result may not.
+// It takes the folded GEMMs of small batches, where the 256x256 tiling is a handful of workgroups on 256 CUs.
+// STAGES = 4 (bf16, launches of at most one workgroup per CU): the LATENCY form of the K loop.  With two stages every K-tile
+// waits for the DMA issued one K-tile earlier -- about 1 us per K-tile when nothing else runs on the CU, 22 K-tiles for the
+// FFN w3 producer of ONE image.  Four stages keep three K-tiles in flight behind counted vmcnt waits; fragment reads are
+// inline-asm ds_read_b128 (hipcc drains vmcnt to 0 in front of an ordinary LDS read while a DMA is in flight).  The MFMA
+// order per output element is unchanged (K-tiles in order, k-halves in order): same bits as STAGES = 2 and as gemm256.hip.
+template <typename T, int EPI, typename OutT, bool FOLD = false, int STAGES = 2>
 __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
+    static_assert(STAGES == 2 || (STAGES == 4 && sizeof(T) == 2), "the four-stage K loop is the bf16 small-batch form");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[STAGES * STAGE_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -96,6 +107,75 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
     stage_tile<T>(A, p.lda, m0, p.M, 0, lds, wave, lane);
     stage_tile<T>(W, p.ldw, n0, p.N, 0, lds + TILE_BYTES, wave, lane);
 
+    // fold coefficients of this lane's rows / columns, requested before the K loop (a small-batch launch has nothing else to
+    // hide their latency behind)
+    [[maybe_unused]] float4 fcc[FOLD ? 4 : 1], fdd[FOLD ? 4 : 1];
+    [[maybe_unused]] float2 fab[FOLD ? 4 : 1];
+    [[maybe_unused]] float2 fpa[FOLD && STAGES == 4 ? 4 : 1][8], fpb[FOLD && STAGES == 4 ? 4 : 1][8];   // raw partial statistics (in-kernel coefficients)
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            fcc[ni] = *reinterpret_cast<const float4*>(p.ln_c + n0 + wn * 64 + ni * 16 + g * 4);
+            fdd[ni] = *reinterpret_cast<const float4*>(p.ln_d + n0 + wn * 64 + ni * 16 + g * 4);
+        }
+        if (STAGES == 4 && p.ln_parts) {                     // launch-uniform: coefficients from the partial statistics, combined after the K loop
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                ln_coef_row_load(reinterpret_cast<const float2*>(p.ln_parts) + (size_t)(m0 + wm * 64 + mi * 16 + l15) * p.ln_nparts, p.ln_nparts,
+                                 fpa[mi], fpb[mi]);
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) fab[mi] = *reinterpret_cast<const float2*>(p.ln_coef + (size_t)(m0 + wm * 64 + mi * 16 + l15) * 2);
+        }
+    }
+
+    if constexpr (STAGES == 4) {
+        // K-tiles 1 and 2 follow tile 0 at once; tile kt + 3 is requested when tile kt is entered (its stage held tile kt - 1,
+        // which every wave has finished reading once it has passed this K-tile's barrier)
+        if (nk > 1) { stage_tile<T>(A, p.lda, m0, p.M, KSTEP, lds + STAGE_BYTES, wave, lane); stage_tile<T>(W, p.ldw, n0, p.N, KSTEP, lds + STAGE_BYTES + TILE_BYTES, wave, lane); }
+        if (nk > 2) { stage_tile<T>(A, p.lda, m0, p.M, 2 * KSTEP, lds + 2 * STAGE_BYTES, wave, lane); stage_tile<T>(W, p.ldw, n0, p.N, 2 * KSTEP, lds + 2 * STAGE_BYTES + TILE_BYTES, wave, lane); }
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+        // per-lane fragment addresses: row (w * 64 + f * 16 + l15), slot (kk * 4 + g) ^ (row & 7); f steps by an immediate
+        const unsigned fa0 = lds_base + (unsigned)(wm * 64 + l15) * ROWB + (unsigned)(((0 + g) ^ (l15 & 7)) << 4);
+        const unsigned fa1 = lds_base + (unsigned)(wm * 64 + l15) * ROWB + (unsigned)(((4 + g) ^ (l15 & 7)) << 4);
+        const unsigned fw0 = lds_base + TILE_BYTES + (unsigned)(wn * 64 + l15) * ROWB + (unsigned)(((0 + g) ^ (l15 & 7)) << 4);
+        const unsigned fw1 = lds_base + TILE_BYTES + (unsigned)(wn * 64 + l15) * ROWB + (unsigned)(((4 + g) ^ (l15 & 7)) << 4);
+#define PM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+        for (int kt = 0; kt < nk; ++kt) {
+            // this wave's 8 DMA instructions of tile kt have landed: at most two younger tiles (16 instructions) stay in flight
+            const int younger = min(nk - 1 - kt, 2);
+            if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 3 < nk) {
+                unsigned char* nxt = lds + ((kt + 3) & 3) * STAGE_BYTES;
+                stage_tile<T>(A, p.lda, m0, p.M, (kt + 3) * KSTEP, nxt, wave, lane);
+                stage_tile<T>(W, p.ldw, n0, p.N, (kt + 3) * KSTEP, nxt + TILE_BYTES, wave, lane);
+            }
+            const unsigned so = (unsigned)(kt & 3) * STAGE_BYTES;
+            typedef unsigned frag_t __attribute__((ext_vector_type(4)));   // (a struct type cannot be a tied asm operand)
+            frag_t af[2][4], wf[2][4];
+            PM_DSR(af[0][0], fa0 + so, 0 * 2048); PM_DSR(af[0][1], fa0 + so, 1 * 2048); PM_DSR(af[0][2], fa0 + so, 2 * 2048); PM_DSR(af[0][3], fa0 + so, 3 * 2048);
+            PM_DSR(wf[0][0], fw0 + so, 0 * 2048); PM_DSR(wf[0][1], fw0 + so, 1 * 2048); PM_DSR(wf[0][2], fw0 + so, 2 * 2048); PM_DSR(wf[0][3], fw0 + so, 3 * 2048);
+            PM_DSR(af[1][0], fa1 + so, 0 * 2048); PM_DSR(af[1][1], fa1 + so, 1 * 2048); PM_DSR(af[1][2], fa1 + so, 2 * 2048); PM_DSR(af[1][3], fa1 + so, 3 * 2048);
+            PM_DSR(wf[1][0], fw1 + so, 0 * 2048); PM_DSR(wf[1][1], fw1 + so, 1 * 2048); PM_DSR(wf[1][2], fw1 + so, 2 * 2048); PM_DSR(wf[1][3], fw1 + so, 3 * 2048);
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(wf[0][0]), "+v"(wf[0][1]),
+                         "+v"(wf[0][2]), "+v"(wf[0][3]));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) Mma<T>::run(acc[mi][ni], __builtin_bit_cast(uint4, wf[0][ni]), __builtin_bit_cast(uint4, af[0][mi]));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]), "+v"(wf[1][0]), "+v"(wf[1][1]),
+                         "+v"(wf[1][2]), "+v"(wf[1][3]));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) Mma<T>::run(acc[mi][ni], __builtin_bit_cast(uint4, wf[1][ni]), __builtin_bit_cast(uint4, af[1][mi]));
+        }
+#undef PM_DSR
+        __builtin_amdgcn_s_barrier();                      // every wave is done with the last K-tile: any stage may serve the epilogue
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         // this wave's DMA for step kt has landed; after the barrier so has everybody's, and every
         // wave has finished reading the other stage (its ds_reads fed MFMAs already issued)
@@ -125,42 +205,79 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
     }
     // the LDS stage that is idle after the K loop (stage nk&1: its last reads finished before the final barrier)
     // is the epilogue's transposition buffer
-    unsigned char* eraw = lds + (nk & 1) * STAGE_BYTES + wave * EPI_WAVE_BYTES;
+    unsigned char* eraw = lds + (STAGES == 4 ? 0 : (nk & 1) * STAGE_BYTES) + wave * EPI_WAVE_BYTES;
+    if constexpr (FOLD && STAGES == 4) {
+        if (p.ln_parts) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                fab[mi] = ln_coef_row(fpa[mi], fpb[mi], p.ln_nparts, p.ln_eps);
+                if (tn == 0 && wn == 0 && g == 0) reinterpret_cast<float2*>(p.ln_coef_out)[(size_t)(m0 + wm * 64 + mi * 16 + l15)] = fab[mi];
+            }
+        }
+    }
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const pk2_t xx = pk_splat(fab[mi].x), yy = pk_splat(fab[mi].y);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) ln_apply4(acc[mi][ni], xx, yy, fcc[ni], fdd[ni]);
+        }
+    }
     if constexpr (EPI == EPI_STD && sizeof(OutT) == 2 && sizeof(T) == 2) {
         if (p.out_lo) { wave_epilogue<EPI, OutT, 4, 1, false, 2>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre); return; }   // bf16 hi/lo residual stream
     }
     wave_epilogue<EPI, OutT, 4>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre);
 }
 
-template <typename T, int EPI, typename OutT>
+int env_int(const char* name, int dflt);
+// at most one workgroup per CU: nothing overlaps the K loop's DMA latency but the loop itself -> the four-stage form
+// (128 KiB of LDS, one workgroup per CU).  PMHIP_GEMM128_DEEP_MAX_TILES (development): 0 = never.
+bool deep128(int tiles, int K) {
+    static const int deep_max = env_int("PMHIP_GEMM128_DEEP_MAX_TILES", 256);
+    return tiles <= deep_max && K >= 4 * 64;
+}
+
+template <typename T, int EPI, typename OutT, bool FOLD = false>
 int launch(const GemmParams& p, hipStream_t s) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     PmTimer tm(gemm_family(p, EPI), s);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, OutT>), dim3(tiles), dim3(THREADS), 0, s, p);
+    if constexpr (sizeof(T) == 2) {
+        if (deep128(tiles, p.K)) {
+            hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, OutT, FOLD, 4>), dim3(tiles), dim3(THREADS), 0, s, p);
+            PM_HIP(hipGetLastError());
+            return PMHIP_OK;
+        }
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, OutT, FOLD>), dim3(tiles), dim3(THREADS), 0, s, p);
     PM_HIP(hipGetLastError());
     return PMHIP_OK;
 }
 
-int g_use256 = -1;      // development switch PMHIP_GEMM256=0 disables the 256x256 kernel
-
-bool use256(const GemmParams& p, int dtype, int epi, int out_dtype) {
-    if (g_use256 < 0) {
-        const char* e = getenv("PMHIP_GEMM256");
-        g_use256 = e ? atoi(e) : 1;
-    }
-    return g_use256 && pm_gemm256_supported(p, dtype, epi, out_dtype);
+// process-wide development switches: read once, in the thread-safe initialiser of a function-local static (the first GEMMs of
+// a process are launched from several lane threads at the same time)
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
-int g_use2b = -1;       // PMHIP_GEMM2B: 0 = never, 1 = where it wins (default), 2 = wherever it is supported (development)
+// A folded GEMM (set_lnfold: M, N multiples of 256) runs on the 128x128 kernel while the 256x256 tiling would leave at least half
+// of the CUs without a workgroup: 4x the workgroups, a quarter of the serial K loop each, bit-identical results.
+// PMHIP_FOLD128_MAX_TILES (development): largest 256x256 tile count that still takes the small kernel (0 = never).
+bool fold_small(const GemmParams& p) {
+    static const int max_tiles = env_int("PMHIP_FOLD128_MAX_TILES", 128);
+    return (p.M / 256) * (p.N / 256) <= max_tiles;
+}
+
+bool use256(const GemmParams& p, int dtype, int epi, int out_dtype) {
+    static const int g_use256 = env_int("PMHIP_GEMM256", 1);      // PMHIP_GEMM256=0 disables the 256x256 kernel
+    return g_use256 && pm_gemm256_supported(p, dtype, epi, out_dtype);
+}
 
 // The two-workgroups-per-CU kernel (gemm2b.hip) takes the residual GEMMs with a short K loop (attention out-proj,
 // K = inner): they are HBM-bound (fp32 residual in, fp32 out) and it streams them at ~4.5 TB/s where the 128x128
 // kernel reaches 3.6.  Everything else measured equal or slower than gemm256.hip (tools/gemm_bench.py).
 bool use2b(const GemmParams& p, int dtype, int epi, int out_dtype) {
-    if (g_use2b < 0) {
-        const char* e = getenv("PMHIP_GEMM2B");
-        g_use2b = e ? atoi(e) : 1;
-    }
+    static const int g_use2b = env_int("PMHIP_GEMM2B", 1);   // 0 = never, 1 = where it wins (default), 2 = wherever it is supported (development)
     if (!g_use2b || !pm_gemm2b_supported(p, dtype, epi, out_dtype)) return false;
     if (g_use2b >= 2) return true;
     return epi == EPI_STD && p.residual && !pm_gemm256_supported(p, dtype, epi, out_dtype);
@@ -180,7 +297,7 @@ int check_common(const GemmParams& p, int dtype) {
 namespace {
 
 // LayerNorm fold (gemm_common.h): checks shared by the three consumer entry points; fills the consumer fields
-int set_lnfold(GemmParams& p, const pmhip_lnfold* ln, int dtype, int epi, int out_dtype) {
+int set_lnfold(GemmParams& p, const pmhip_lnfold* ln, int dtype, int epi, int out_dtype, pmhip_stream stream) {
     if (!ln) return PMHIP_OK;
     PM_REQUIRE(ln->coef && ln->c && ln->d, "gemm_ln: null fold pointer");
     PM_REQUIRE(dtype == PMHIP_BF16, "gemm_ln: the LayerNorm fold exists in bf16 mode only");
@@ -190,6 +307,17 @@ int set_lnfold(GemmParams& p, const pmhip_lnfold* ln, int dtype, int epi, int ou
     PM_REQUIRE(p.M % 256 == 0 && p.N % 256 == 0 && (unsigned long long)p.M * p.lda * 2 < (1ull << 31) &&
                (unsigned long long)p.N * p.ldw * 2 < (1ull << 31),
                "gemm_ln: shape M=%d N=%d K=%d is not served by the 256x256 kernel (M, N multiples of 256)", p.M, p.N, p.K);
+    if (ln->parts) {
+        // coef is an OUTPUT too: computed from the producer's partial statistics -- by the GEMM's own prologue where the small
+        // kernel takes the launch (one launch less per LayerNorm: 424 launches of 5 us per 8-step generate of one image), by
+        // pmhip_ln_coef_parts in front of it otherwise.  Same bits either way (common.h, lnp_*).
+        PM_REQUIRE(ln->nparts > 0 && ln->nparts <= 16 && ln->nparts * 64 == p.K, "gemm_ln: nparts=%d does not describe K=%d columns", ln->nparts, p.K);
+        if (fold_small(p) && deep128(ceil_div(p.M, BM) * ceil_div(p.N, BN), p.K)) {
+            p.ln_parts = ln->parts; p.ln_nparts = ln->nparts; p.ln_eps = ln->eps; p.ln_coef_out = const_cast<float*>(ln->coef);
+        } else {
+            PM_TRY(pmhip_ln_coef_parts(ln->parts, ln->nparts, ln->eps, const_cast<float*>(ln->coef), p.M, stream));
+        }
+    }
     return PMHIP_OK;
 }
 
@@ -207,8 +335,9 @@ int gemm_impl(int dtype, const void* A, int lda, const void* W, int ldw, const f
     PM_REQUIRE(!residual || out_dtype == PMHIP_F32, "gemm: a residual needs an f32 output (the residual stream is f32)");
     PM_REQUIRE(out_dtype == PMHIP_F32 || out_dtype == dtype, "gemm: out dtype must be f32 or the compute dtype");
     PM_REQUIRE(out_dtype == PMHIP_F32 || ldo % 8 == 0, "gemm: bf16 output needs ldo to be a multiple of 8");
-    PM_TRY(set_lnfold(p, ln, dtype, EPI_STD, out_dtype));
+    PM_TRY(set_lnfold(p, ln, dtype, EPI_STD, out_dtype, stream));
     hipStream_t s = (hipStream_t)stream;
+    if (ln && fold_small(p)) return out_dtype == PMHIP_F32 ? launch<bf16_t, EPI_STD, float, true>(p, s) : launch<bf16_t, EPI_STD, bf16_t, true>(p, s);
     if (ln) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
     if (use2b(p, dtype, EPI_STD, out_dtype)) return pm_gemm2b_launch(p, EPI_STD, out_dtype, s);
     if (use256(p, dtype, EPI_STD, out_dtype)) return pm_gemm256_launch(p, EPI_STD, out_dtype, s);
@@ -293,8 +422,9 @@ static int gemm_swiglu_impl(int dtype, const void* A, int lda, const void* W12p,
     PM_TRY(check_common(p, dtype));
     PM_REQUIRE(Hp % 64 == 0, "gemm_swiglu: padded hidden width %d must be a multiple of 64", Hp);
     PM_REQUIRE(b12p && out && ldo % 8 == 0, "gemm_swiglu: bias/out required, ldo multiple of 8");
-    PM_TRY(set_lnfold(p, ln, dtype, EPI_SWIGLU, dtype));
+    PM_TRY(set_lnfold(p, ln, dtype, EPI_SWIGLU, dtype, stream));
     hipStream_t s = (hipStream_t)stream;
+    if (ln && fold_small(p)) return launch<bf16_t, EPI_SWIGLU, bf16_t, true>(p, s);
     if (ln) return pm_gemm256_launch(p, EPI_SWIGLU, dtype, s);
     if (use2b(p, dtype, EPI_SWIGLU, dtype)) return pm_gemm2b_launch(p, EPI_SWIGLU, dtype, s);
     if (use256(p, dtype, EPI_SWIGLU, dtype)) return pm_gemm256_launch(p, EPI_SWIGLU, dtype, s);
@@ -331,8 +461,9 @@ static int gemm_heads_impl(int dtype, const void* A, int lda, const void* W, int
         PM_REQUIRE(p.kinds[i] >= 0 && p.kinds[i] <= 2, "gemm_heads: bad part kind");
     }
     PM_TRY(check_common(p, dtype));
-    PM_TRY(set_lnfold(p, ln, dtype, EPI_HEADS, dtype));
+    PM_TRY(set_lnfold(p, ln, dtype, EPI_HEADS, dtype, stream));
     hipStream_t s = (hipStream_t)stream;
+    if (ln && fold_small(p)) return launch<bf16_t, EPI_HEADS, bf16_t, true>(p, s);
     if (ln) return pm_gemm256_launch(p, EPI_HEADS, dtype, s);
     if (use2b(p, dtype, EPI_HEADS, dtype)) return pm_gemm2b_launch(p, EPI_HEADS, dtype, s);
     if (use256(p, dtype, EPI_HEADS, dtype)) return pm_gemm256_launch(p, EPI_HEADS, dtype, s);

@@ -24,6 +24,8 @@
 // vmcnt waits (odd slots) are slot-aligned for all waves, which keeps the vmcnt arithmetic identical.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "gemm_common.h"
 
 using namespace pmgemm;
@@ -326,19 +328,30 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     }
 }
 
-int g_chunk256 = -1;
+// Process-wide tuning knobs of this kernel (development: tools/chunk_sweep.sh, tools/env_sweep.sh), read from the environment
+// exactly ONCE, under std::call_once: the first launches of a process come from several lane threads at the same time.
+struct Knobs256 {
+    int chunk = 6;          // PMHIP_CHUNK256: width of the L2-aware tile walk
+    int persist = 256;      // PMHIP_PERSIST256: workgroups of the persistent grid (0 = one per tile)
+    int res_kmin = 1024;    // PMHIP_G256_RES_KMIN: shortest K at which a residual GEMM takes this kernel
+};
+const Knobs256& knobs256() {
+    static Knobs256 k;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (const char* e = getenv("PMHIP_CHUNK256")) k.chunk = atoi(e);
+        if (const char* e = getenv("PMHIP_PERSIST256")) k.persist = atoi(e);
+        if (const char* e = getenv("PMHIP_G256_RES_KMIN")) k.res_kmin = atoi(e);
+    });
+    return k;
+}
 
 template <int EPI, typename OutT>
 int launch256(const GemmParams& p0, hipStream_t s) {
-    if (g_chunk256 < 0) {
-        const char* e = getenv("PMHIP_CHUNK256");
-        g_chunk256 = e ? atoi(e) : 6;
-    }
     GemmParams p = p0;
-    p.chunk = g_chunk256;
+    p.chunk = knobs256().chunk;
     const int tiles = (p.M / BM) * (p.N / BN);
-    static int persist = -1;                     // PMHIP_PERSIST256: workgroups of the persistent grid (0 = one per tile)
-    if (persist < 0) { const char* e = getenv("PMHIP_PERSIST256"); persist = e ? atoi(e) : 256; }
+    const int persist = knobs256().persist;
     const int grid = (persist > 0 && tiles > persist) ? persist : tiles;
     if (p.ln_coef && p.out_lo) { pm_set_error("gemm256: a hi/lo residual producer cannot have a LayerNorm folded in"); return PMHIP_EINVAL; }
     PmTimer tm(gemm_family(p, EPI), s);
@@ -358,9 +371,7 @@ int pm_gemm256_supported(const GemmParams& p, int dtype, int epi, int out_dtype)
     if (epi == EPI_STD && p.residual) {
         // residual GEMMs: the 128x128 kernel prefetches the residual tile and overlaps two workgroups per CU, which wins
         // while the GEMM is HBM-bound (small K); with a long K loop the faster main loop of this kernel wins
-        static int kmin = -1;
-        if (kmin < 0) { const char* e = getenv("PMHIP_G256_RES_KMIN"); kmin = e ? atoi(e) : 1024; }
-        if (p.K < kmin) return 0;
+        if (p.K < knobs256().res_kmin) return 0;
     }
     (void)out_dtype;
     return 1;

@@ -144,14 +144,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm2b_kernel(const GemmParams p) 
     }
 }
 
-int g_chunk2b = -1;
-
 template <int EPI, typename OutT>
 int launch2b(const GemmParams& p0, hipStream_t s) {
-    if (g_chunk2b < 0) {
-        const char* e = getenv("PMHIP_CHUNK2B");
-        g_chunk2b = e ? atoi(e) : 12;
-    }
+    // PMHIP_CHUNK2B (development): read once, in the thread-safe initialiser of a function-local static
+    static const int g_chunk2b = [] { const char* e = getenv("PMHIP_CHUNK2B"); return e ? atoi(e) : 12; }();
     GemmParams p = p0;
     p.chunk = g_chunk2b;
     const int tiles = (p.M / BM) * (p.N / BN);

@@ -48,6 +48,10 @@ struct GemmParams {
     // applies out = rstd * acc - rstd * mean * c[n] + d[n]
     const float* ln_coef;                          // [M][2]: (rstd, -rstd * mean) per row, from pmhip_ln_coef
     const float* ln_c; const float* ln_d;          // [N]: c = sum_k bf16(gamma_k W_nk), d = sum_k beta_k W_nk
+    // small-batch form (128x128 kernel only): the coefficients are computed in the prologue from the producer's partial statistics
+    // (ln_coef_row, common.h) instead of being read; the workgroups of the first tile column also store them to ln_coef_out for
+    // whoever needs them next (the centred producer that follows)
+    const float* ln_parts; int ln_nparts; float ln_eps; float* ln_coef_out;
 };
 
 // timing family of a launch (common.h)

@@ -363,14 +363,14 @@ __global__ __launch_bounds__(THREADS) void ln_coef_parts_kernel(const float2* __
     const float2* pr = parts + (size_t)(live ? row : 0) * nparts;
     const float2 p0 = (live && j < nparts) ? pr[j] : make_float2(0.f, 0.f);
     const float2 p1 = (live && j + 8 < nparts) ? pr[j + 8] : make_float2(0.f, 0.f);
-    float s = p0.x + p1.x;
-    s += dpp_mov<0xB1>(s); s += dpp_mov<0x4E>(s); s += dpp_mov<0x141>(s);
-    const float mean = s / (float)(nparts * 64);
-    const float d0 = p0.x * (1.0f / 64.0f) - mean, d1 = p1.x * (1.0f / 64.0f) - mean;
-    float m2 = (j < nparts ? p0.y + 64.0f * d0 * d0 : 0.f) + (j + 8 < nparts ? p1.y + 64.0f * d1 * d1 : 0.f);
-    m2 += dpp_mov<0xB1>(m2); m2 += dpp_mov<0x4E>(m2); m2 += dpp_mov<0x141>(m2);
-    const float rstd = 1.0f / sqrtf(m2 / (float)(nparts * 64) + eps);
-    if (live && j == 0) coef[row] = make_float2(rstd, -rstd * mean);
+    // the arithmetic is common.h's (lnp_*): the butterfly below is lnp_tree8's ((0+1)+(2+3)) + ((4+5)+(6+7)), and a lane-pair sum
+    // is commutative -- ln_coef_row (one lane per row, in the small-batch folded GEMM) gives the same bits
+    float s = __fadd_rn(p0.x, p1.x);
+    s = __fadd_rn(s, dpp_mov<0xB1>(s)); s = __fadd_rn(s, dpp_mov<0x4E>(s)); s = __fadd_rn(s, dpp_mov<0x141>(s));
+    const float mean = lnp_mean(s, nparts);
+    float m2 = __fadd_rn(j < nparts ? lnp_m2_term(p0, mean) : 0.f, j + 8 < nparts ? lnp_m2_term(p1, mean) : 0.f);
+    m2 = __fadd_rn(m2, dpp_mov<0xB1>(m2)); m2 = __fadd_rn(m2, dpp_mov<0x4E>(m2)); m2 = __fadd_rn(m2, dpp_mov<0x141>(m2));
+    if (live && j == 0) coef[row] = lnp_finish(m2, mean, nparts, eps);
 }
 
 template <bool IN_HILO, int MODE>

@@ -74,8 +74,18 @@ def _pack_tower(layers, dtype, keep, stage2):
     return arr, hp
 
 
+def _switch_dict(bits):
+    return {"ln_fold": bool(bits & 1), "hilo": bool(bits & 2), "ln_stats": bool(bits & 4), "hilo_center": bool(bits & 8),
+            "blocking_wait": bool(bits & 16)}
+
+
 class VqganEngine:
     """native VQModel handle (pmhip_vqgan) for one (weights, dtype, device)."""
+
+    @property
+    def switches(self):
+        """the PMHIP_* switches this handle latched when it was created (they are not re-read: include/pmhip.h)"""
+        return _switch_dict(self.lib.pmhip_vqgan_switches(self.handle))
 
     def __init__(self, model, dtype):
         self.lib = _lib.load()
@@ -196,6 +206,11 @@ class VqganEngine:
 
 class S2Engine:
     """native CondTransformer handle (pmhip_s2) + the MaskGIT loop entry points."""
+
+    @property
+    def switches(self):
+        """the PMHIP_* switches this handle latched when it was created (they are not re-read: include/pmhip.h)"""
+        return _switch_dict(self.lib.pmhip_s2_switches(self.handle))
 
     def __init__(self, transformer, codebook, mask_token, dtype):
         self.lib = _lib.load()

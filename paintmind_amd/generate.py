@@ -9,6 +9,7 @@ ALL positions, confidence from the unfiltered softmax, >= 1 token re-masked on t
 The masked-token objective (forward / loss / random_masking, generate.py:78-146) is built forward-only: no backward.
 """
 import math
+import concurrent.futures
 import os
 
 import numpy as np
@@ -400,8 +401,13 @@ class Pipeline(nn.Module):
             pool = _lane_thread_pool(streams)
             futs = [pool.submit(run_lane, i, e, v, st) for i, (e, v, st) in enumerate(lanes)]
             # wait for EVERY lane before a failure is reported: the other lanes keep copying into the caller's host buffer
-            # until their native call returns
-            done = [(f.exception(), f) for f in futs]
+            # until their native call returns.  That includes an exception delivered to THIS thread while it waits (a
+            # KeyboardInterrupt): the lane threads are inside the native call and cannot be cancelled, so the caller's
+            # cleanup (which retires the host buffer) may only run once they have all returned.
+            try:
+                done = [(f.exception(), f) for f in futs]
+            finally:
+                concurrent.futures.wait(futs)
             for err, _ in done:
                 if err is not None:
                     raise err
@@ -460,7 +466,10 @@ class Pipeline(nn.Module):
             streams = 2 if (self.compute_dtype == torch.bfloat16 and B >= 8) else 1
             env_streams = os.environ.get("PMHIP_GENERATE_STREAMS")
             if env_streams:
-                streams = max(1, int(env_streams))
+                try:
+                    streams = max(1, min(int(env_streams), B))   # never more lanes than images
+                except ValueError:
+                    pass                                          # not a number: keep the default
         flags = [step % save_interval == 0 for step in range(timesteps)]
         if context is not None:
             context = context.to(eng.device)

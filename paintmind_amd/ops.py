@@ -228,10 +228,15 @@ def ln_coef(hi, eps=1e-5):
     return coef
 
 
-def _lnfold(coef, c, d):
+def _lnfold(coef, c, d, parts=None, eps=1e-5):
+    """coef [M,2] is an input, or -- with `parts` [M, K/64, 2] (the producer's partial statistics) -- an OUTPUT the call fills"""
     ln = _lib.LnFold()
     ln.coef, ln.c, ln.d = coef.data_ptr(), c.data_ptr(), d.data_ptr()
-    ln._keep = (coef, c, d)
+    if parts is not None:
+        if parts.dtype != torch.float32 or not parts.is_contiguous() or parts.shape[0] != coef.shape[0] or parts.shape[-1] != 2:
+            raise ValueError("fold parts must be a contiguous fp32 [M, K/64, 2] tensor")
+        ln.parts, ln.nparts, ln.eps = parts.data_ptr(), parts.shape[1], float(eps)
+    ln._keep = (coef, c, d, parts)
     return ln
 
 
@@ -239,34 +244,34 @@ def lnfold_supported(kind, M, N, K):
     return bool(_lib.load().pmhip_lnfold_supported(BF16, kind, M, N, K))
 
 
-def gemm_ln(xb, wg, coef, c, d, bias=None, out_dtype=None):
+def gemm_ln(xb, wg, coef, c, d, bias=None, out_dtype=None, parts=None):
     dev = _dev(xb, wg, coef, c, d)
     lib = _lib.load()
     M, K = xb.shape
     N = wg.shape[0]
     out_dtype = out_dtype or xb.dtype
     out = torch.empty(M, N, device=dev, dtype=out_dtype)
-    ln = _lnfold(coef, c, d)
+    ln = _lnfold(coef, c, d, parts)
     with torch.cuda.device(dev):
         check(lib.pmhip_gemm_ln(pm_dtype(xb.dtype), _p(xb), xb.stride(0), _p(wg), wg.stride(0), _p(bias), _p(out), N,
                                 pm_dtype(out_dtype), M, N, K, C.byref(ln), stream_ptr(dev)), "pmhip_gemm_ln")
     return out
 
 
-def gemm_swiglu_ln(xb, w12pg, b12p, coef, c, d):
+def gemm_swiglu_ln(xb, w12pg, b12p, coef, c, d, parts=None):
     dev = _dev(xb, w12pg, b12p)
     lib = _lib.load()
     M, K = xb.shape
     Hp = w12pg.shape[0] // 2
     out = torch.empty(M, Hp, device=dev, dtype=xb.dtype)
-    ln = _lnfold(coef, c, d)
+    ln = _lnfold(coef, c, d, parts)
     with torch.cuda.device(dev):
         check(lib.pmhip_gemm_swiglu_ln(pm_dtype(xb.dtype), _p(xb), xb.stride(0), _p(w12pg), _p(b12p), _p(out), Hp, M, Hp, K,
                                        C.byref(ln), stream_ptr(dev)), "pmhip_gemm_swiglu_ln")
     return out
 
 
-def gemm_heads_ln(xb, wg, heads, tokens, kinds, q_scale, coef, c, d):
+def gemm_heads_ln(xb, wg, heads, tokens, kinds, q_scale, coef, c, d, parts=None):
     dev = _dev(xb, wg)
     lib = _lib.load()
     M, K = xb.shape
@@ -278,7 +283,7 @@ def gemm_heads_ln(xb, wg, heads, tokens, kinds, q_scale, coef, c, d):
         outs.append(torch.empty(shape, device=dev, dtype=xb.dtype))
     kinds_c = (C.c_int * len(kinds))(*kinds)
     outs_c = (C.c_void_p * len(kinds))(*[o.data_ptr() for o in outs])
-    ln = _lnfold(coef, c, d)
+    ln = _lnfold(coef, c, d, parts)
     with torch.cuda.device(dev):
         check(lib.pmhip_gemm_heads_ln(pm_dtype(xb.dtype), _p(xb), xb.stride(0), _p(wg), wg.stride(0), M, K, heads, tokens, tp,
                                       len(kinds), kinds_c, outs_c, float(q_scale), C.byref(ln), stream_ptr(dev)),

@@ -20,6 +20,21 @@ namespace gen3 {
 namespace gen4 {
 #include "../../paintmind_amd/csrc/attention_bf16.hip"
 }
+#define PM_ATTN_FORCE_QF 4
+namespace g4_qf4 {
+#include "../../paintmind_amd/csrc/attention_bf16.hip"
+}
+#undef PM_ATTN_FORCE_QF
+#define PM_ATTN_FORCE_QF 2
+namespace g4_qf2 {
+#include "../../paintmind_amd/csrc/attention_bf16.hip"
+}
+#undef PM_ATTN_FORCE_QF
+#define PM_ATTN_FORCE_QF 1
+namespace g4_qf1 {
+#include "../../paintmind_amd/csrc/attention_bf16.hip"
+}
+#undef PM_ATTN_FORCE_QF
 #define PM_ATTN_RING 3
 namespace g4_ring3 {
 #include "../../paintmind_amd/csrc/attention_bf16.hip"
@@ -73,6 +88,8 @@ int main(int argc, char** argv) {
     hipMalloc(&q, n * 2); hipMalloc(&k, n * 2); hipMalloc(&v, n * 2); hipMalloc(&o, n * 2); hipMalloc(&oref, n * 2);
     hipMemcpy(q, hq.data(), n * 2, hipMemcpyHostToDevice); hipMemcpy(k, hk.data(), n * 2, hipMemcpyHostToDevice); hipMemcpy(v, hv.data(), n * 2, hipMemcpyHostToDevice);
     V vs[] = {{"gen3 (round 4)", gen3::pm_attention_bf16, true, 0}, {"gen4", gen4::pm_attention_bf16, true, 0},
+              {"gen4 256 queries / WG", g4_qf4::pm_attention_bf16, true, 0}, {"gen4 128 queries / WG", g4_qf2::pm_attention_bf16, true, 0},
+              {"gen4  64 queries / WG", g4_qf1::pm_attention_bf16, true, 0},
               {"gen4 3-stage ring", g4_ring3::pm_attention_bf16, true, 0},
               {"gen4 no exp (mul)", g4_noexp::pm_attention_bf16, false, 0}, {"gen4 no fragment reads", g4_noreads::pm_attention_bf16, false, 0},
               {"gen4 no DMA", g4_nodma::pm_attention_bf16, false, 0}, {"gen4 no barrier", g4_nobarrier::pm_attention_bf16, false, 0},
@@ -91,6 +108,19 @@ int main(int argc, char** argv) {
         if (fabs(fa) > maxv) maxv = fabs(fa);
     }
     printf("gen4 vs gen3: %zu of %zu bf16 outputs differ, max abs diff %.3g (max |out| %.3g)\n", ndiff, n, maxd, maxv);
+    {   // the workgroup size must not change a single bit (batch invariance of the model rests on it)
+        fn_t qfs[3] = {g4_qf4::pm_attention_bf16, g4_qf2::pm_attention_bf16, g4_qf1::pm_attention_bf16};
+        const char* names[3] = {"256", "128", "64"};
+        for (int i = 0; i < 3; ++i) {
+            hipMemset(oref, 0xff, n * 2);
+            qfs[i](q, k, v, oref, H * 64, B, H, N, N, N, 1, 0);
+            hipDeviceSynchronize();
+            hipMemcpy(ha.data(), oref, n * 2, hipMemcpyDeviceToHost);
+            size_t nd = 0;
+            for (size_t j = 0; j < n; ++j) nd += ha[j] != hb[j];
+            printf("gen4 (%s queries per workgroup) vs gen4 (auto): %zu of %zu outputs differ\n", names[i], nd, n);
+        }
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int round = 0; round < rounds; ++round)
         for (auto& x : vs) {
