@@ -432,7 +432,9 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
             const int q = q0 + it * 8 + (lane >> 3);
             if (q < Nq && ((mask >> (it >> 1)) & 1u) && (!(ABL & 32) || q < 0)) {
                 const v4u_t v = *reinterpret_cast<const v4u_t*>(obuf + rd_off + it * 8 * RS);
-                __builtin_nontemporal_store(v, reinterpret_cast<v4u_t*>(rowbase + (lane_off + (unsigned)(it * 8) * (unsigned)ldo * 2u)));
+                v4u_t* dst = reinterpret_cast<v4u_t*>(rowbase + (lane_off + (unsigned)(it * 8) * (unsigned)ldo * 2u));
+                if constexpr (QF == 4) __builtin_nontemporal_store(v, dst);   // large launches stream their output past the caches;
+                else *dst = v;                                                 // a small one is read at once by the next kernel of the chain
             }
         }
     };

@@ -209,6 +209,8 @@ int check_dim_head(const char* who, const pmhip_tower_cfg& tc) {
 // The PMHIP_* switches are read ONCE, when a handle is created (a handle's graphs, workspace and fold decisions all depend on
 // them; a getenv on the hot path is also a data race with a caller that edits the environment from another thread).
 struct Switches {
+    int overlap_rows = 16384;   // PMHIP_DECODE_OVERLAP_MAX_ROWS: largest B * tokens whose decode loop defers each step's ViT decode
+                                // to a side stream beside the next step's tower (0 = never)
     bool hilo = true;       // PMHIP_HILO=0: the fp32 stream + LayerNorm kernel of rounds 1-2
     bool fold = true;       // PMHIP_LN_UNFOLD=1: the hi/lo pair, but the separate LayerNorm kernel
     bool stats = true;      // PMHIP_LN_STATS=0: fold coefficients by a pass over the hi plane
@@ -226,6 +228,8 @@ struct Switches {
         w.center = !(e && atoi(e) == 0);
         e = getenv("PMHIP_BLOCKING_WAIT");
         w.blocking_wait = e && atoi(e) != 0;
+        e = getenv("PMHIP_DECODE_OVERLAP_MAX_ROWS");
+        if (e) w.overlap_rows = atoi(e);
         return w;
     }
     int fold_rows_cap = 0;  // PMHIP_FOLD_MAX_ROWS (development / tests): cap on the rows one folded launch takes, see fold_rows()
@@ -643,6 +647,10 @@ struct pmhip_s2 {
     bool pos_split = false;         // bf16 mode: position embedding split into hi / lo planes (ws "pos.*")
     std::map<std::string, GraphEntry> graphs;   // captured decode loops, keyed by shape / schedule structure
     hipStream_t capture_stream = nullptr;       // capture never happens on the caller's stream (it may be the NULL stream)
+    // small batches: the ViT decode of step t runs on a side stream BESIDE the tower of step t + 1 (fork / join by events, inside
+    // the captured graphs too)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // per-call scalars travel through PINNED host slots (a pageable source makes hipMemcpyAsync stage synchronously);
     // a slot is reused only after the copy that read it has completed
     static constexpr int kParamSlots = 4;
@@ -657,6 +665,9 @@ struct pmhip_s2 {
     ~pmhip_s2() {
         for (auto& kv : graphs) kv.second.destroy();
         if (capture_stream) (void)hipStreamDestroy(capture_stream);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
         if (params_host) (void)hipHostFree(params_host);
         for (auto e : params_done)
             if (e) (void)hipEventDestroy(e);
@@ -760,16 +771,15 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s, b
 // Pipeline.sample after the context is prepared (generate.py:161-179)
 // guidance != nullptr: the step's logits are uncond + *guidance * (cond - uncond), uncond = the same tower without the context
 // (the branch the reference trains by dropping the text, utils/trainer.py:379,387-388); everything after the logits is unchanged
-int sample_step(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, int B, int topk, float temperature, int num_mask,
-                const float* noise, uint64_t seed, uint32_t step, uint64_t image_base, float* img_out, int64_t* pred_out,
-                float* score_out, hipStream_t s, const PmGenParams* gp = nullptr, const float* guidance = nullptr) {
+// The step in two halves, so that a caller can put something between the tower and the sampling (the small-batch loop joins the
+// previous step's decode there).  step_tower: ids2tokens + the tower(s) -> logits.  step_tail: sampling, the optional decode,
+// the optional copies, re-masking.
+int step_tower(pmhip_s2* s2, const int64_t* ids, int B, hipStream_t s, const float* guidance) {
     const auto& c = s2->cfg;
     const int M = B * c.tokens;
-    void* tp; float* logits; int64_t* pred; float* score;
+    void* tp; float* logits;
     WS(s2->ws, "s2.tok", (size_t)M * 64 * dtype_size(s2->dtype), tp);
     WS(s2->ws, "s2.logits", (size_t)M * c.n_embed * 4, logits);
-    WS(s2->ws, "s2.pred", (size_t)M * 8, pred);
-    WS(s2->ws, "s2.score", (size_t)M * 4, score);
     // ids2tokens: lookup in cat(raw codebook, mask_token) (generate.py:148-157)
     PM_TRY(pmhip_embed_rows(s2->w.tok_table, ids, tp, s2->dtype, 64, M, c.n_embed + 1, c.embed_dim, s));
     PM_TRY(s2_tower(s2, tp, B, logits, s));
@@ -779,15 +789,39 @@ int sample_step(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, int B, int topk, fl
         PM_TRY(s2_tower(s2, tp, B, uncond, s, false));
         PM_TRY(pmhip_guidance_combine(logits, uncond, *guidance, logits, (size_t)M * c.n_embed, s));
     }
+    return PMHIP_OK;
+}
+
+// the image of the predictions the last step_tail left in the handle's `s2.pred` (decoded from pred at ALL positions, generate.py:165)
+int decode_pred(pmhip_s2* s2, pmhip_vqgan* vq, int B, float* img_out, hipStream_t s) {
+    PM_REQUIRE(vq, "pipeline_sample: img_out requested without a vqgan handle");
+    int64_t* pred;
+    WS(s2->ws, "s2.pred", (size_t)B * s2->cfg.tokens * 8, pred);
+    return vq_decode_indices(vq, pred, B, img_out, s);
+}
+
+int step_tail(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, int B, int topk, float temperature, int num_mask, const float* noise,
+              uint64_t seed, uint32_t step, uint64_t image_base, float* img_out, int64_t* pred_out, float* score_out, hipStream_t s,
+              const PmGenParams* gp) {
+    const auto& c = s2->cfg;
+    const int M = B * c.tokens;
+    float* logits; int64_t* pred; float* score;
+    WS(s2->ws, "s2.logits", (size_t)M * c.n_embed * 4, logits);
+    WS(s2->ws, "s2.pred", (size_t)M * 8, pred);
+    WS(s2->ws, "s2.score", (size_t)M * 4, score);
     PM_TRY(pm_sample_rows(logits, c.n_embed, ids, (int64_t)c.n_embed, topk, temperature, noise, seed, step,
                           image_base * (uint64_t)c.tokens, pred, ids, score, M, c.n_embed, gp, s));
-    if (img_out) {
-        PM_REQUIRE(vq, "pipeline_sample: img_out requested without a vqgan handle");
-        PM_TRY(vq_decode_indices(vq, pred, B, img_out, s));      // decoded from pred at ALL positions (generate.py:165)
-    }
+    if (img_out) PM_TRY(decode_pred(s2, vq, B, img_out, s));
     if (pred_out) PM_HIP(hipMemcpyAsync(pred_out, pred, (size_t)M * 8, hipMemcpyDeviceToDevice, s));
     if (score_out) PM_HIP(hipMemcpyAsync(score_out, score, (size_t)M * 4, hipMemcpyDeviceToDevice, s));
     return pm_remask(ids, score, num_mask, (int64_t)c.n_embed, B, c.tokens, gp, (int)step, s);
+}
+
+int sample_step(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, int B, int topk, float temperature, int num_mask,
+                const float* noise, uint64_t seed, uint32_t step, uint64_t image_base, float* img_out, int64_t* pred_out,
+                float* score_out, hipStream_t s, const PmGenParams* gp = nullptr, const float* guidance = nullptr) {
+    PM_TRY(step_tower(s2, ids, B, s, guidance));
+    return step_tail(s2, vq, ids, B, topk, temperature, num_mask, noise, seed, step, image_base, img_out, pred_out, score_out, s, gp);
 }
 
 }  // namespace
@@ -941,29 +975,63 @@ static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const 
     }
     key += "d";
     for (int t = 0; t < T; ++t) key += (decode_host && decode_host[t]) ? '1' : '0';
+
+    // A unit = one executable graph.  Normally a unit is a SEGMENT [t0, t1) (t1 - 1 is a decoded step, or the end of the loop) whose
+    // last step decodes in place and whose image is complete when the unit is.  Small batches (B * tokens <= overlap_rows: every
+    // kernel is a few dozen workgroups on 256 CUs and the loop is one long dependent chain) DEFER the decode instead: the ViT decode
+    // of a segment's last step opens the NEXT unit on a side stream, beside that unit's first tower pass (which only needs the ids),
+    // and is joined before the first sampling kernel overwrites the predictions it reads; a last unit without steps decodes the
+    // final image.  Same kernels, same inputs: bit-identical images, one unit later.
+    struct Unit { int t0, t1, decode_first, delivers; bool decode_inline; };
+    const bool overlap = vq && n_dec > 0 && s2->sw.overlap_rows > 0 && (long long)B * s2->cfg.tokens <= s2->sw.overlap_rows;
+    std::vector<Unit> units;
+    {
+        int d = 0, pend = -1;
+        for (int t = 0, t0 = 0; t < T; ++t) {
+            const bool dec = decode_host && decode_host[t];
+            if (!dec && t != T - 1) continue;
+            if (overlap) { units.push_back({t0, t + 1, pend, pend, false}); pend = dec ? d++ : -1; }
+            else units.push_back({t0, t + 1, -1, dec ? d++ : -1, true});
+            t0 = t + 1;
+        }
+        if (pend >= 0) units.push_back({T, T, pend, pend, false});
+    }
+    key += overlap ? "o1" : "o0";
     GraphEntry& ge = s2->graphs[key];
+    if (overlap && !s2->side_stream) {
+        PM_HIP(hipStreamCreateWithFlags(&s2->side_stream, hipStreamNonBlocking));
+        PM_HIP(hipEventCreateWithFlags(&s2->ev_fork, hipEventDisableTiming));
+        PM_HIP(hipEventCreateWithFlags(&s2->ev_join, hipEventDisableTiming));
+    }
 
-    std::vector<std::pair<int, int>> segs;                    // [t0, t1): t1 - 1 is a decoded step, or the end of the loop
-    for (int t = 0, t0 = 0; t < T; ++t)
-        if ((decode_host && decode_host[t]) || t == T - 1) { segs.emplace_back(t0, t + 1); t0 = t + 1; }
-
-    // d0 = number of images decoded before step t0
-    auto run_steps = [&](hipStream_t on, int t0, int t1, int d0) -> int {
-        int d = d0;
-        for (int t = t0; t < t1; ++t) {
-            float* img = (decode_host && decode_host[t]) ? gimgs + (size_t)(d++) * img_elems : nullptr;
-            PM_TRY(sample_step(s2, vq, gids, B, topk, 0.f, 0, nullptr, 0, (uint32_t)t, 0, img, nullptr, nullptr, on, gparams, guidance));
+    auto run_unit = [&](hipStream_t on, const Unit& u) -> int {
+        bool need_join = false;
+        if (u.decode_first >= 0) {
+            float* img = gimgs + (size_t)u.decode_first * img_elems;
+            if (u.t1 > u.t0) {                                // fork: the pending decode runs beside this unit's first tower pass
+                PM_HIP(hipEventRecord(s2->ev_fork, on));
+                PM_HIP(hipStreamWaitEvent(s2->side_stream, s2->ev_fork, 0));
+                PM_TRY(decode_pred(s2, vq, B, img, s2->side_stream));
+                PM_HIP(hipEventRecord(s2->ev_join, s2->side_stream));
+                need_join = true;
+            } else {
+                PM_TRY(decode_pred(s2, vq, B, img, on));
+            }
+        }
+        for (int t = u.t0; t < u.t1; ++t) {
+            PM_TRY(step_tower(s2, gids, B, on, guidance));
+            if (need_join) { PM_HIP(hipStreamWaitEvent(on, s2->ev_join, 0)); need_join = false; }   // before `s2.pred` is overwritten
+            float* img = (u.decode_inline && decode_host && decode_host[t]) ? gimgs + (size_t)u.delivers * img_elems : nullptr;
+            PM_TRY(step_tail(s2, vq, gids, B, topk, 0.f, 0, nullptr, 0, (uint32_t)t, 0, img, nullptr, nullptr, on, gparams));
         }
         return PMHIP_OK;
     };
-    auto seg_decodes = [&](int i) { return decode_host && decode_host[segs[i].second - 1]; };
 
     if (!ge.warmed) {
-        int d = 0;
-        for (size_t i = 0; i < segs.size(); ++i) {             // eager once: sizes every workspace buffer
-            PM_TRY(run_steps(s, segs[i].first, segs[i].second, d));
+        for (const Unit& u : units) {                          // eager once: sizes every workspace buffer
+            PM_TRY(run_unit(s, u));
             PM_TRY(flush_pending());
-            if (seg_decodes((int)i)) { PM_TRY(deliver(d, gimgs + (size_t)d * img_elems)); ++d; }
+            if (u.delivers >= 0) PM_TRY(deliver(u.delivers, gimgs + (size_t)u.delivers * img_elems));
         }
         ge.warmed = true;
     } else {
@@ -976,8 +1044,7 @@ static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const 
         if (ge.segs.empty()) {
             if (!s2->capture_stream) PM_HIP(hipStreamCreateWithFlags(&s2->capture_stream, hipStreamNonBlocking));
             hipStream_t cap = s2->capture_stream;
-            int d = 0;
-            for (size_t i = 0; i < segs.size(); ++i) {
+            for (const Unit& u : units) {
                 hipGraph_t g = nullptr;
                 hipGraphExec_t exec = nullptr;
                 s2->ws.frozen = true;
@@ -985,7 +1052,7 @@ static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const 
                 hipError_t rc = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
                 int step_rc = PMHIP_OK;
                 if (rc == hipSuccess) {
-                    step_rc = run_steps(cap, segs[i].first, segs[i].second, d);   // records only: nothing executes during capture
+                    step_rc = run_unit(cap, u);              // records only: nothing executes during capture
                     rc = hipStreamEndCapture(cap, &g);
                 }
                 s2->ws.frozen = false;
@@ -998,16 +1065,14 @@ static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const 
                     PM_HIP(rc);
                 }
                 ge.segs.push_back(exec);
-                if (seg_decodes((int)i)) ++d;
             }
             ge.s2_gen = s2->ws.gen;
             ge.vq_gen = vq ? vq->ws.gen : 0;
         }
-        int d = 0;
-        for (size_t i = 0; i < segs.size(); ++i) {
+        for (size_t i = 0; i < units.size(); ++i) {
             PM_HIP(hipGraphLaunch(ge.segs[i], s));
             PM_TRY(flush_pending());
-            if (seg_decodes((int)i)) { PM_TRY(deliver(d, gimgs + (size_t)d * img_elems)); ++d; }
+            if (units[i].delivers >= 0) PM_TRY(deliver(units[i].delivers, gimgs + (size_t)units[i].delivers * img_elems));
         }
     }
     PM_HIP(hipMemcpyAsync(ids, gids, ids_bytes, hipMemcpyDeviceToDevice, s));

@@ -224,9 +224,9 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
         }
     }
     if constexpr (EPI == EPI_STD && sizeof(OutT) == 2 && sizeof(T) == 2) {
-        if (p.out_lo) { wave_epilogue<EPI, OutT, 4, 1, false, 2>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre); return; }   // bf16 hi/lo residual stream
+        if (p.out_lo) { wave_epilogue<EPI, OutT, 4, 1, false, 2, NoHook, STAGES != 4>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre); return; }   // bf16 hi/lo residual stream
     }
-    wave_epilogue<EPI, OutT, 4>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre);
+    wave_epilogue<EPI, OutT, 4, RPRE ? 16 : 1, false, -1, NoHook, STAGES != 4>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre);
 }
 
 int env_int(const char* name, int dflt);

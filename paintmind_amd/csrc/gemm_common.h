@@ -211,8 +211,18 @@ __device__ __forceinline__ void nt_store_row(bf16_t* p, const float (&v)[8]) {
     nt_store16(p, make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])));
 }
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// NT = false (the small-batch launches of gemm.hip): ordinary stores.  There the whole output is a megabyte that the NEXT kernel of
+// the dependent chain reads at once: it should stay in the cache hierarchy instead of being streamed past it.
+template <bool NT> __device__ __forceinline__ void st16(void* p, uint4 v) {
+    if constexpr (NT) nt_store16(p, v);
+    else *reinterpret_cast<uint4*>(p) = v;
+}
+template <bool NT> __device__ __forceinline__ void st_row(float* p, const float (&v)[4]) { st16<NT>(p, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]))); }
+template <bool NT> __device__ __forceinline__ void st_row(bf16_t* p, const float (&v)[8]) {
+    st16<NT>(p, make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])));
+}
 
-template <int EPI, typename OutT, int MI, int NPRE, bool FULL = false, int RES = -1, typename Hook = NoHook>
+template <int EPI, typename OutT, int MI, int NPRE, bool FULL = false, int RES = -1, typename Hook = NoHook, bool NT = true>
 __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][4], unsigned char* eraw, int mwave,
                                               int nw, int lane, const float4 (&rpre)[NPRE], Hook hook = Hook()) {
     constexpr int CPL = 16 / (int)sizeof(OutT);                    // columns per lane per store (16 B)
@@ -253,7 +263,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                     const size_t vstep = (size_t)8 * p.tokens_pad;
 #pragma unroll
                     for (int it = 0; it < 8; ++it)                               // 8 d-rows x 128 B per store instruction
-                        nt_store16(vptr + it * vstep, *reinterpret_cast<const uint4*>(lptr + it * 1024));
+                        st16<NT>(vptr + it * vstep, *reinterpret_cast<const uint4*>(lptr + it * 1024));
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 } else {
@@ -337,7 +347,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slice mi staged; the reads of slice mi-1 (other buffer) returned
             const uint4 v = *reinterpret_cast<const uint4*>(eraw + (mi & 1) * BUFB + erow * RS + q * 16);
             if (mi + 1 < MI) stage(mi + 1);
-            nt_store16(reinterpret_cast<OutT*>(p.out) + (size_t)(mwave + mi * 16 + erow) * p.ldo + (nw >> 1) + q * 8, v);
+            st16<NT>(reinterpret_cast<OutT*>(p.out) + (size_t)(mwave + mi * 16 + erow) * p.ldo + (nw >> 1) + q * 8, v);
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -375,7 +385,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                 const int r = mi * 16 + it * 8 + (lane >> 3);
                 int b = b0, t = t0 + r;
                 if (!nowrap) { b = (mwave + r) / p.tokens; t = (mwave + r) % p.tokens; }
-                nt_store16(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + (lane & 7) * 8, v[it]);
+                st16<NT>(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + (lane & 7) * 8, v[it]);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -461,7 +471,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int erow = lane >> 2, q = lane & 3, m = mbase + erow;
             if (FULL || m < p.M)                                   // 4 lanes x 16 B = the row's 32 hidden columns
-                nt_store16(reinterpret_cast<OutT*>(p.out) + (size_t)m * p.ldo + (nw >> 1) + q * 8, *reinterpret_cast<const uint4*>(eraw + erow * RS + q * 16));
+                st16<NT>(reinterpret_cast<OutT*>(p.out) + (size_t)m * p.ldo + (nw >> 1) + q * 8, *reinterpret_cast<const uint4*>(eraw + erow * RS + q * 16));
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             continue;
@@ -486,7 +496,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                 const int r = it * 8 + (lane >> 3), mm = mbase + r, c16 = lane & 7;
                 if (FULL || mm < p.M) {
                     const int b = mm / p.tokens, t = mm % p.tokens;
-                    nt_store16(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + c16 * 8, *reinterpret_cast<const uint4*>(eraw + r * RS + c16 * 16));
+                    st16<NT>(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + c16 * 8, *reinterpret_cast<const uint4*>(eraw + r * RS + c16 * 16));
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -542,8 +552,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                         if (mm < 0)
 #endif
                         {
-                        nt_store16(reinterpret_cast<bf16_t*>(p.out) + (size_t)mm * p.ldo + ncol, make_uint4(oh[0], oh[1], oh[2], oh[3]));
-                        nt_store16(p.out_lo + (size_t)mm * p.ldo + ncol, make_uint4(ol[0], ol[1], ol[2], ol[3]));
+                        st16<NT>(reinterpret_cast<bf16_t*>(p.out) + (size_t)mm * p.ldo + ncol, make_uint4(oh[0], oh[1], oh[2], oh[3]));
+                        st16<NT>(p.out_lo + (size_t)mm * p.ldo + ncol, make_uint4(ol[0], ol[1], ol[2], ol[3]));
                         }
                         if (p.row_stats) {                          // wave-uniform.  The 8 lanes of a row hold its 64 hi values of this wave
                             float hv[8];
@@ -570,7 +580,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                             v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                         }
                     }
-                    nt_store_row(reinterpret_cast<OutT*>(p.out) + (size_t)mm * p.ldo + ncol, v);
+                    st_row<NT>(reinterpret_cast<OutT*>(p.out) + (size_t)mm * p.ldo + ncol, v);
                 }
             }
         } else if constexpr (EPI == EPI_SWIGLU) {
@@ -616,7 +626,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                         const float4 t4 = *reinterpret_cast<const float4*>(ebuf + r * ESTRIDE + ccol + j);
                         v[j] = t4.x * sc; v[j + 1] = t4.y * sc; v[j + 2] = t4.z * sc; v[j + 3] = t4.w * sc;
                     }
-                    nt_store_row(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + ccol, v);
+                    st_row<NT>(dst + (((size_t)b * p.heads + h) * tstride + t) * 64 + ccol, v);
                 }
             }
         }
