@@ -34,7 +34,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-USE_GRAPH = os.environ.get("PM_BENCH_NO_GRAPH", "0") != "1"   # decode loop = one replayed hipGraph (captured during warm-up)
+# A RANK of a multi-GPU job (WORLD_SIZE > 1) runs the loop eagerly under AMD_DIRECT_DISPATCH=0 (set HERE, before anything loads the
+# HIP runtime): with direct dispatch the runtime's helper thread busy-polls for as long as graph work is outstanding -- a full core per
+# rank, 8.2 of this pool's 16 cores for 8 ranks -- without it the helper sleeps (measured on one GPU, same box: 471.1 vs 470.9 images/s,
+# 0.12 vs 1.02 cores per rank; profiles/r05_c_host_polling.txt).  hipGraph replay is NOT usable in that runtime mode on ROCm 7.2
+# (tools/hwtests/graph_dispatch_mode.hip: 39 of 40 replays of a chain of dependent kernels wrong, with no code of this repository
+# involved), so the rank loop is the eager one -- bit-identical results, and at B = 64 per rank its launches hide behind the kernels.
+# PM_BENCH_RANK_GRAPH=1 keeps direct dispatch + graph replay in ranks.  A single-GPU run (the headline) is unchanged: graph replay.
+_RANK_MODE = int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("PM_BENCH_RANK_GRAPH", "0") != "1"
+if _RANK_MODE:
+    os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
+USE_GRAPH = os.environ.get("PM_BENCH_NO_GRAPH", "0") != "1" and os.environ.get("AMD_DIRECT_DISPATCH", "1") != "0"   # decode loop = replayed hipGraphs (captured during warm-up)
 STREAMS = int(os.environ.get("PM_BENCH_STREAMS", "2"))   # concurrent micro-batches per GPU (1 = one stream); 2 measured best
 LANE_SPLIT = os.environ.get("PM_BENCH_LANE_SPLIT")       # development: explicit micro-batch sizes, e.g. "32,16,16"
 PACE = int(os.environ.get("PM_BENCH_PACE", "2"))        # steps the host may run ahead of the GPU in the timed loop

@@ -151,6 +151,24 @@ struct Workspace {
 #define WS(ws, name, bytes, ptr) PM_TRY((ws).get(name, (size_t)(bytes), (void**)&(ptr), s))
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Stream-ordered copy of 16-byte words by a KERNEL (device memory, or pinned host memory through its device alias).  The graph-replayed
+// decode loop refreshes its per-call parameter block and ids with it: with AMD_DIRECT_DISPATCH=0 (the runtime mode whose helper
+// thread sleeps instead of busy-polling, which is what a rank of an 8-GPU job on a 16-core host wants) a hipMemcpyAsync in front of
+// a hipGraphLaunch on the same stream was observed NOT to be ordered before the graph's first kernels (tools/dispatch_mode_stress.py:
+// 12-16 of 18 replays read the previous call's seed / ids; 0 of 18 with direct dispatch, 0 of 18 eager in either mode).  A kernel
+// is a queue packet like the graph's own kernels and cannot be overtaken.
+__global__ void copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int copy16_async(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    PM_REQUIRE(bytes % 16 == 0 && ((uintptr_t)dst | (uintptr_t)src) % 16 == 0, "copy16: %zu bytes / pointers not 16-byte aligned", bytes);
+    const size_t n16 = bytes / 16;
+    const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 1024);
+    hipLaunchKernelGGL(copy16_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, n16);
+    PM_HIP(hipGetLastError());
+    return PMHIP_OK;
+}
 constexpr float kLog2e = 1.4426950408889634f;
 
 struct CrossKV {            // cached cross-attention K / V^T of a static context, per layer
@@ -877,7 +895,11 @@ static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const 
     for (int t = 0; t < T; ++t) n_dec += (decode_host && decode_host[t]) ? 1 : 0;
     PM_REQUIRE(n_dec == 0 || (vq && (imgs_out || imgs_host)), "pipeline_generate: decode requested without vqgan / an image destination");
     PM_REQUIRE(!imgs_host || host_stride >= img_elems, "pipeline_generate: host_stride smaller than one image batch");
-    const bool graph = use_graph && !g_pm_timing_on.load() && T <= PM_MAX_STEPS;
+    // AMD_DIRECT_DISPATCH=0 (the runtime mode without the busy-polling helper thread): hipGraph replay is broken there on ROCm 7.2
+    // -- tools/hwtests/graph_dispatch_mode.hip, 39 of 40 replays of a chain of dependent kernels wrong with none of this library's
+    // code involved -- so the loop stays eager in that mode whatever the caller asked for (same results, bit for bit)
+    static const bool direct_dispatch_off = [] { const char* e = getenv("AMD_DIRECT_DISPATCH"); return e && atoi(e) == 0; }();
+    const bool graph = use_graph && !g_pm_timing_on.load() && T <= PM_MAX_STEPS && !direct_dispatch_off;
 
     if (imgs_host) {
         // PMHIP_BLOCKING_WAIT=1 (read when the handle is created): the lane's host thread SLEEPS in hipEventSynchronize while its
@@ -961,9 +983,13 @@ static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const 
     hp.seed = seed;
     hp.row_base = image_base * (uint64_t)s2->cfg.tokens;
     for (int t = 0; t < T; ++t) { hp.temps[t] = temps_host[t]; hp.nmask[t] = nmask_host[t]; }
-    PM_HIP(hipMemcpyAsync(gparams, &hp, sizeof hp, hipMemcpyHostToDevice, s));
+    {
+        void* hp_dev = nullptr;                               // the pinned slot through its device alias
+        PM_HIP(hipHostGetDevicePointer(&hp_dev, &hp, 0));
+        PM_TRY(copy16_async(gparams, hp_dev, sizeof hp, s));
+    }
     PM_HIP(hipEventRecord(s2->params_done[slot], s));
-    PM_HIP(hipMemcpyAsync(gids, ids, ids_bytes, hipMemcpyDeviceToDevice, s));
+    PM_TRY(copy16_async(gids, ids, ids_bytes, s));
 
     std::string key = "B" + std::to_string(B) + "T" + std::to_string(T) + "k" + std::to_string(topk) + "L" +
                       std::to_string(context ? L : 0) + "v" + std::to_string(vq ? vq->uid : 0) + "f" +
@@ -1075,7 +1101,7 @@ static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const 
             if (units[i].delivers >= 0) PM_TRY(deliver(units[i].delivers, gimgs + (size_t)units[i].delivers * img_elems));
         }
     }
-    PM_HIP(hipMemcpyAsync(ids, gids, ids_bytes, hipMemcpyDeviceToDevice, s));
+    PM_TRY(copy16_async(ids, gids, ids_bytes, s));
     return flush_pending();
 }
 
