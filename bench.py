@@ -1016,10 +1016,10 @@ def main():
             # against THAT clock next to the nominal one (which stays the contract)
             log("per-kernel shader clock probe")
             clocks = kernel_clock_probe(device)
-            fam_of = {"attention": "attention", "EPI_HEADS": "gemm_heads", "EPI_SWIGLU": "gemm_swiglu", "bf16 hi/lo": "gemm_resid",
-                      "gemm2b": "gemm_resid2b", "f32>": "gemm_plain"}
+            fam_of = (("gemm2b", "gemm_resid2b"), ("EPI_HEADS", "gemm_heads"), ("EPI_SWIGLU", "gemm_swiglu"), ("bf16 hi/lo", "gemm_resid"),
+                      ("f32>", "gemm_plain"), ("attention_bf16_kernel", "attention"))
             for b in by_kernel:
-                fam_key = next((v for k_, v in fam_of.items() if k_ in b["kernel"]), None)
+                fam_key = next((v for k_, v in fam_of if k_ in b["kernel"]), None)
                 ck = clocks.get(fam_key)
                 if ck:
                     b.update(ck)

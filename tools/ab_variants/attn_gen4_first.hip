@@ -71,6 +71,7 @@ namespace {
 constexpr int KT = 64;        // keys per tile
 constexpr int DH = 64;
 constexpr int THREADS = 256;
+constexpr int QF = 4;         // 16-query tiles per wave
 constexpr int TILE_BYTES = KT * 128;
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;              // K tile + V^T tile
 #ifndef PM_ATTN_RING
@@ -96,12 +97,7 @@ __device__ __forceinline__ f32x4_t mma(const v4u_t& rows, const v4u_t& cols, con
 #define LGKM4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 #define LGKM2(n, a, b) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b))
 
-// QF = 16-query tiles per wave: 4 (256 queries per workgroup) wherever that fills the chip; 2 and 1 (128 / 64 queries per
-// workgroup) for small batches, where a grid of 256-query workgroups leaves most CUs idle (B = 1, H = 8, N = 1024: 32
-// workgroups of 41 us each).  The arithmetic of a 16-query tile does not depend on QF or on its neighbours in the workgroup
-// (same MFMA chains, same half-tile order, the fallback below decided per tile), so an image's result does not depend on the
-// batch it runs in.
-template <bool EXP2, int QF>
+template <bool EXP2>
 __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
                                                                     const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
                                                                     int ldo, int heads, int Nq, int Nkv, int Nkv_pad, int nqb) {
@@ -147,7 +143,6 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
     const unsigned vfrag_lane0 = lds_base + 8192u + (unsigned)l15 * 128u + (unsigned)(((0 + g) ^ (l15 & 7)) << 4);
     const unsigned vfrag_lane1 = lds_base + 8192u + (unsigned)l15 * 128u + (unsigned)(((4 + g) ^ (l15 & 7)) << 4);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int q0u = qblk * (4 * QF * 16) + wave_u * (QF * 16);       // q0, provably wave-uniform
 
     // one K tile + one V^T tile by DMA, 1 KiB per wave-instruction; the bank swizzle (slot ^ row) is applied to the SOURCE
     // address (kvoff / vvoff) and again on the read side
@@ -234,6 +229,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
             const float mold = first ? -INFINITY : -negm[qf][0];
             const float mb = first ? 0.f : mold;             // what the accumulators started from
             const float mnew = vmax3(mold, group4_max(m) + mb, -1e30f);   // column max over the 4 lane groups
+            const float alpha = EXP2 ? __builtin_amdgcn_exp2f(mold - mnew) : expf(mold - mnew);
             const float delta = mb - mnew;                   // scores hold s - mb: move them to s - mnew
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -246,13 +242,10 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
             } else {
                 negm[qf][0] += delta; negm[qf][1] += delta; negm[qf][2] += delta; negm[qf][3] += delta;
             }
-            if constexpr (!first) {                          // (the first half-tile finds l = O = 0: nothing to move)
-                const float alpha = EXP2 ? __builtin_amdgcn_exp2f(mold - mnew) : expf(mold - mnew);
-                lacc[qf][0] *= alpha; lacc[qf][1] *= alpha; lacc[qf][2] *= alpha; lacc[qf][3] *= alpha;
+            lacc[qf][0] *= alpha; lacc[qf][1] *= alpha; lacc[qf][2] *= alpha; lacc[qf][3] *= alpha;
 #pragma unroll
-                for (int df = 0; df < 4; ++df) {
-                    o[df][qf][0] *= alpha; o[df][qf][1] *= alpha; o[df][qf][2] *= alpha; o[df][qf][3] *= alpha;
-                }
+            for (int df = 0; df < 4; ++df) {
+                o[df][qf][0] *= alpha; o[df][qf][1] *= alpha; o[df][qf][2] *= alpha; o[df][qf][3] *= alpha;
             }
         }
     };
@@ -303,14 +296,14 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
                 e[kk][r] = (ABL & 1) ? sc[kk][qf][r] * 1.0001f : (EXP2 ? __builtin_amdgcn_exp2f(sc[kk][qf][r]) : expf(sc[kk][qf][r]));   // sc = s - m
         pf[qf] = v4u_t{pack_bf16x2(e[0][0], e[0][1]), pack_bf16x2(e[0][2], e[0][3]), pack_bf16x2(e[1][0], e[1][1]), pack_bf16x2(e[1][2], e[1][3])};
     };
-    // P.V and the row sums of one half-tile (exact path)
-    auto pv_all = [&]() {
+    // P.V for two 16-row blocks of O^T and two of the four row-sum tiles (exact path)
+    auto pv2 = [&](int d0) {
 #pragma unroll
-        for (int df = 0; df < 4; ++df)
+        for (int qf = 0; qf < QF; ++qf) o[d0][qf] = mma(vf[d0], pf[qf], o[d0][qf]);
 #pragma unroll
-            for (int qf = 0; qf < QF; ++qf) o[df][qf] = mma(vf[df], pf[qf], o[df][qf]);
-#pragma unroll
-        for (int qf = 0; qf < QF; ++qf) lacc[qf] = mma(ones, pf[qf], lacc[qf]);
+        for (int qf = 0; qf < QF; ++qf) o[d0 + 1][qf] = mma(vf[d0 + 1], pf[qf], o[d0 + 1][qf]);
+        lacc[d0] = mma(ones, pf[d0], lacc[d0]);
+        lacc[d0 + 1] = mma(ones, pf[d0 + 1], lacc[d0 + 1]);
     };
 
     // One half-tile h of the FAST path, query-tile-major.  On entry sA = S^T(h) - m_ref (tiles 1..3 untouched, tile 0 already
@@ -331,13 +324,13 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
         for (int df = 0; df < 4; ++df) o[df][g] = mma(vf[df], pf[g], o[df][g]);
         lacc[g] = mma(ones, pf[g], lacc[g]);
     };
-    auto grp_sched = [&](bool last) {                        // 9 MFMAs, 8 transcendentals, 4 packs: M T T M P  x4, M  (last group: M T T P)
+    auto grp_sched = [&]() {                                 // 9 MFMAs, 8 transcendentals, 4 packs: M T T M P  x4, M
         if constexpr (EXP2 && !(ABL & 1)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-                if (!last) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -347,28 +340,49 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
         constexpr bool OPENS = decltype(opens_c)::value;
         const unsigned va = (((hh + 1) & 1) ? vfrag_lane1 : vfrag_lane0) + (unsigned)(((hh + 1) >> 1) % RING) * STAGE_BYTES;
         const unsigned ka = kfrag_lane + (unsigned)(((hh + 2) >> 1) % RING) * STAGE_BYTES + (unsigned)(hh & 1) * 4096u;
+        // ---- group 0
+        LGKM4(4, kf[0][0], kf[0][1], kf[1][0], kf[1][1]);
+        grp_mma(sc, 0);
+        LGKM4(0, vf[0], vf[1], vf[2], vf[3]);
+        grp_pv(0);
+        exp_pack1(sc, 1);
+        grp_sched();
+        asm volatile("" : "+v"(pf[1]));                          // the packs are complete here (not sunk to their first use)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- group 1
+        grp_mma(sc, 1);
+        grp_pv(1);
+        exp_pack1(sc, 2);
+        grp_sched();
+        asm volatile("" : "+v"(pf[2]));
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- group 2
+        grp_mma(sc, 2);
+        grp_pv(2);
+        exp_pack1(sc, 3);
+        grp_sched();
+        asm volatile("" : "+v"(pf[3]));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (OPENS) enter_tile(std::false_type{}, (hh + 2) >> 1);
+        // ---- group 3: the fragment registers are handed over to the next half-tile as they die
+        grp_mma(sc, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        DSRX(kf[0][0], ka, 0 * 512 + 0 * 64); DSRX(kf[0][1], ka, 0 * 512 + 1 * 64);
+        DSRX(kf[1][0], ka, 1 * 512 + 1 * 64); DSRX(kf[1][1], ka, 1 * 512 + 0 * 64);
+        grp_pv(3);
+        exp_pack1(sc, 0);
+        if constexpr (EXP2 && !(ABL & 1)) {
 #pragma unroll
-        for (int g = 0; g < QF; ++g) {
-            const bool last = g == QF - 1;
-            if (OPENS && last) enter_tile(std::false_type{}, (hh + 2) >> 1);
-            if (g == 0) LGKM4(4, kf[0][0], kf[0][1], kf[1][0], kf[1][1]);          // K(h+1) landed; the V^T(h) reads are younger
-            grp_mma(sc, g);
-            if (last) {                                       // the fragment registers are handed over to the next half-tile as they die
-                __builtin_amdgcn_sched_barrier(0);
-                DSRX(kf[0][0], ka, 0 * 512 + 0 * 64); DSRX(kf[0][1], ka, 0 * 512 + 1 * 64);
-                DSRX(kf[1][0], ka, 1 * 512 + 1 * 64); DSRX(kf[1][1], ka, 1 * 512 + 0 * 64);
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
             }
-            if (g == 0) {
-                if (last) LGKM4(4, vf[0], vf[1], vf[2], vf[3]);                     // (QF = 1: the K(h+2) reads just issued stay in flight)
-                else LGKM4(0, vf[0], vf[1], vf[2], vf[3]);
-            }
-            grp_pv(g);
-            exp_pack1(sc, (g + 1) % QF);                      // last group: P(h+1, 0), from the S^T(h+1, 0) of this step's group 0
-            grp_sched(last);
-            asm volatile("" : "+v"(pf[(g + 1) % QF]));            // the packs are complete here (not sunk to their first use)
-            __builtin_amdgcn_sched_barrier(0);
-            if (last) { DSRX(vf[0], va, 0 * 2048); DSRX(vf[1], va, 1 * 2048); DSRX(vf[2], va, 2 * 2048); DSRX(vf[3], va, 3 * 2048); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
+        asm volatile("" : "+v"(pf[0]));
+        __builtin_amdgcn_sched_barrier(0);
+        DSRX(vf[0], va, 0 * 2048); DSRX(vf[1], va, 1 * 2048); DSRX(vf[2], va, 2 * 2048); DSRX(vf[3], va, 3 * 2048);
     };
 
     // The exact path, one half-tile with every condition at run time, full waits and the running max raised at once: first and
@@ -386,7 +400,8 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
         if (next2) k_issue(kf, hh + 2);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(kf[0][0]), "+v"(kf[0][1]),
                      "+v"(kf[1][0]), "+v"(kf[1][1]));
-        pv_all();
+        pv2(0);
+        pv2(2);
         if (next) rescale(std::true_type{}, std::false_type{}, sA, hh + 1);
     };
 
@@ -402,42 +417,6 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
     const bool all_steady = (Nkv % KT) == 0 && ntiles >= 3;
     const int steady_end = all_steady ? nhalves - 1 : min(nhalves - 3, nh_full - 2);   // one bound: the loop's shape is unchanged
     bool exact = steady_end <= 0;                            // workgroup-uniform: no fast step at all, or second attempt
-    unsigned redo_mask = ~0u;                                // tiles the exact attempt stores (all, unless it is a second attempt)
-
-    // O = O^T / l, head-major inside the output row, for the 16-query tiles in `mask`.  The wave's output rows go through the
-    // (idle) K / V^T ring, so that every global store instruction writes 8 whole 128-byte rows (non-temporal)
-    auto finalize = [&](unsigned mask) {
-        constexpr int RS = 144;                              // staged row: 64 bf16 + pad, 16-B aligned, conflict-free
-        unsigned char* obuf = lds + wave * (QF * 16 * RS);
-#pragma unroll
-        for (int qf = 0; qf < QF; ++qf) {
-            const float inv = 1.0f / lacc[qf][0];
-#pragma unroll
-            for (int df = 0; df < 4; ++df)
-                *reinterpret_cast<uint2*>(obuf + (qf * 16 + l15) * RS + (df * 16 + g * 4) * 2) =
-                    make_uint2(pack_bf16x2(o[df][qf][0] * inv, o[df][qf][1] * inv), pack_bf16x2(o[df][qf][2] * inv, o[df][qf][3] * inv));
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // wave-uniform 64-bit base + one 32-bit lane offset: nothing lane-dependent and 64 bits wide for the compiler to hoist to
-        // the kernel entry and spill around the loop
-        unsigned char* rowbase = reinterpret_cast<unsigned char*>(out + ((size_t)b * Nq + q0u) * ldo + h * DH);
-        unsigned lane_off = ((unsigned)(lane >> 3) * (unsigned)ldo + (unsigned)(lane & 7) * 8u) * 2u;
-        unsigned rd_off = (unsigned)(lane >> 3) * RS + (unsigned)(lane & 7) * 16u;
-        // (this lambda sits inside the attempt loop: without the opaque moves the per-row addresses are loop-invariant, get hoisted
-        // to the kernel entry -- 30 registers -- and are spilled around the K loop)
-        asm volatile("" : "+v"(lane_off), "+v"(rd_off));
-#pragma unroll
-        for (int it = 0; it < QF * 2; ++it) {                // 8 rows x 128 B per store instruction
-            const int q = q0 + it * 8 + (lane >> 3);
-            if (q < Nq && ((mask >> (it >> 1)) & 1u) && (!(ABL & 32) || q < 0)) {
-                const v4u_t v = *reinterpret_cast<const v4u_t*>(obuf + rd_off + it * 8 * RS);
-                v4u_t* dst = reinterpret_cast<v4u_t*>(rowbase + (lane_off + (unsigned)(it * 8) * (unsigned)ldo * 2u));
-                if constexpr (QF == 4) __builtin_nontemporal_store(v, dst);   // large launches stream their output past the caches;
-                else *dst = v;                                                 // a small one is read at once by the next kernel of the chain
-            }
-        }
-    };
 
     for (;;) {
 #pragma unroll
@@ -474,60 +453,61 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
         for (; hs < nhalves; ++hs) slow_step(hs);
 
         // every wave is done reading the ring; and the vote: did a probability of the fast path leave the f32 range?
-        unsigned badmask = 0;                                // wave-uniform: bit qf = tile qf of this wave overflowed
+        bool bad = false;
         if (!exact && !(ABL & 6)) {                          // (ablations that compute garbage do not vote)
 #pragma unroll
-            for (int qf = 0; qf < QF; ++qf) badmask |= __any(!(lacc[qf][0] < 1.8446744e19f)) ? (1u << qf) : 0u;     // 2^64; NaN fails too
-            if (lane == 0) redo_vote[wave] = (int)badmask;
+            for (int qf = 0; qf < QF; ++qf) bad |= !(lacc[qf][0] < 1.8446744e19f);     // 2^64; NaN fails too
+            const int vote = __any(bad) ? 1 : 0;
+            if (lane == 0) redo_vote[wave] = vote;
         }
         __syncthreads();
         if (exact) break;
         const int4 votes = *reinterpret_cast<const int4*>(redo_vote);
-        if (__builtin_expect(__builtin_amdgcn_readfirstlane(votes.x | votes.y | votes.z | votes.w) == 0, 1)) break;
-        // Rare: some 16-query tile of this workgroup overflowed.  The good tiles are stored now, from the fast path (a tile's
-        // result never depends on its neighbours); the workgroup then runs again through the exact path and stores the others.
+        if (__builtin_amdgcn_readfirstlane(votes.x | votes.y | votes.z | votes.w) == 0) break;
         if (tid == 0) atomicAdd(&g_attn_fallbacks, 1ull);
-        finalize(~badmask);
-        redo_mask = badmask;
         exact = true;                                        // (the exact attempt does not vote: no write races the read above)
-        __syncthreads();                                     // the staging area is the ring: every wave has read its rows back
     }
-    finalize(redo_mask);                                     // the common case: every tile, straight from the fast path
+
+    // ---- finalize: O = O^T / l, head-major inside the output row.  The wave's 64 output rows go through the (now idle)
+    // K / V^T ring, so that every global store instruction writes 8 whole 128-byte rows (non-temporal)
+    constexpr int RS = 144;                                // staged row: 64 bf16 + pad, 16-B aligned, conflict-free
+    unsigned char* obuf = lds + wave * (64 * RS);
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        const float inv = 1.0f / lacc[qf][0];
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+            *reinterpret_cast<uint2*>(obuf + (qf * 16 + l15) * RS + (df * 16 + g * 4) * 2) =
+                make_uint2(pack_bf16x2(o[df][qf][0] * inv, o[df][qf][1] * inv), pack_bf16x2(o[df][qf][2] * inv, o[df][qf][3] * inv));
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < QF * 2; ++it) {                  // 8 rows x 128 B per store instruction
+        const int r = it * 8 + (lane >> 3), c16 = lane & 7, q = q0 + r;
+        if (q < Nq && (!(ABL & 32) || q < 0)) {
+            const v4u_t v = *reinterpret_cast<const v4u_t*>(obuf + r * RS + c16 * 16);
+            __builtin_nontemporal_store(v, reinterpret_cast<v4u_t*>(out + ((size_t)b * Nq + q) * ldo + h * DH + c16 * 8));
+        }
+    }
 }
 
 #undef DSRX
 #undef LGKM4
 #undef LGKM2
 
-template <int QF>
-static void launch_qf(const void* Q, const void* K, const void* Vt, void* out, int ldo, int B, int heads, int Nq, int Nkv, int Nkv_pad,
-                      int use_exp2, hipStream_t s) {
+}  // namespace
+
+// bf16 leg of pmhip_attention (attention.hip): arguments already validated there
+int pm_attention_bf16(const void* Q, const void* K, const void* Vt, void* out, int ldo, int B, int heads, int Nq, int Nkv,
+                      int Nkv_pad, int use_exp2, hipStream_t s) {
     const int nqb = ceil_div(Nq, 4 * QF * 16);
     dim3 grid(nqb * B * heads), block(THREADS);
     if (use_exp2)
-        hipLaunchKernelGGL((attention_bf16_kernel<true, QF>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt,
+        hipLaunchKernelGGL((attention_bf16_kernel<true>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt,
                            (bf16_t*)out, ldo, heads, Nq, Nkv, Nkv_pad, nqb);
     else
-        hipLaunchKernelGGL((attention_bf16_kernel<false, QF>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt,
+        hipLaunchKernelGGL((attention_bf16_kernel<false>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt,
                            (bf16_t*)out, ldo, heads, Nq, Nkv, Nkv_pad, nqb);
-}
-
-}  // namespace
-
-// bf16 leg of pmhip_attention (attention.hip): arguments already validated there.  The largest workgroup that still gives the
-// chip two workgroups per CU (256 CUs on this part: 512) is taken; the result of an image does not depend on the choice.
-int pm_attention_bf16(const void* Q, const void* K, const void* Vt, void* out, int ldo, int B, int heads, int Nq, int Nkv,
-                      int Nkv_pad, int use_exp2, hipStream_t s) {
-#ifdef PM_ATTN_FORCE_QF
-    constexpr int kFill = 0;
-    const int force = PM_ATTN_FORCE_QF;
-#else
-    constexpr int kFill = 512;
-    const int force = 0;
-#endif
-    const long long bh = (long long)B * heads;
-    if (force == 4 || (!force && bh * ceil_div(Nq, 256) >= kFill)) launch_qf<4>(Q, K, Vt, out, ldo, B, heads, Nq, Nkv, Nkv_pad, use_exp2, s);
-    else if (force == 2 || (!force && bh * ceil_div(Nq, 128) >= kFill)) launch_qf<2>(Q, K, Vt, out, ldo, B, heads, Nq, Nkv, Nkv_pad, use_exp2, s);
-    else launch_qf<1>(Q, K, Vt, out, ldo, B, heads, Nq, Nkv, Nkv_pad, use_exp2, s);
     return PMHIP_OK;
 }
