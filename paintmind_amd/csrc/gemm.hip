@@ -32,12 +32,12 @@ constexpr int TILE_BYTES = 128 * ROWB;             // one operand tile, 16 KiB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;        // A tile + W tile
 constexpr int THREADS = 256;
 
-template <typename T>
+template <typename T, int CH = 4>                          // CH = 16 / waves: 8-row chunks of the 128-row tile per wave
 __device__ __forceinline__ void stage_tile(const T* __restrict__ base, int ld, int row0, int rows_total,
                                            int k0, unsigned char* lds_tile, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int chunk = wave * 4 + i;                    // 1 KiB = 8 rows x 128 B
+    for (int i = 0; i < CH; ++i) {
+        const int chunk = wave * CH + i;                   // 1 KiB = 8 rows x 128 B
         const int r = chunk * 8 + (lane >> 3);
         const int slot = (lane & 7) ^ (r & 7);             // inverse swizzle on the source
         int gr = row0 + r;
@@ -58,9 +58,15 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ base, int ld, i
 // FFN w3 producer of ONE image.  Four stages keep three K-tiles in flight behind counted vmcnt waits; fragment reads are
 // inline-asm ds_read_b128 (hipcc drains vmcnt to 0 in front of an ordinary LDS read while a DMA is in flight).  The MFMA
 // order per output element is unchanged (K-tiles in order, k-halves in order): same bits as STAGES = 2 and as gemm256.hip.
-template <typename T, int EPI, typename OutT, bool FOLD = false, int STAGES = 2>
-__global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
+// WM = waves along m (x 2 along n).  WM = 4 (the latency form only): EIGHT waves, two per SIMD, each 32 x 64 of the tile: a wave
+// issues half of the LDS-DMA instructions per K-tile (with four waves a K-tile cost 0.57 us for 0.23 us of MFMA) and its SIMD
+// partner computes meanwhile.
+template <typename T, int EPI, typename OutT, bool FOLD = false, int STAGES = 2, int WM = 2>
+__global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const GemmParams p) {
     static_assert(STAGES == 2 || (STAGES == 4 && sizeof(T) == 2), "the four-stage K loop is the bf16 small-batch form");
+    static_assert(WM == 2 || (WM == 4 && STAGES == 4), "eight waves only in the latency form");
+    constexpr int MI = 8 / WM;                          // 16-row accumulator tiles per wave (wave tile = MI*16 x 64)
+    constexpr int CH = 8 / WM;                          // 8-row DMA chunks per wave and operand
     __shared__ __attribute__((aligned(1024))) unsigned char lds[STAGES * STAGE_BYTES];
 
     const int tid = threadIdx.x;
@@ -79,24 +85,24 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
     constexpr int KSTEP = ROWB / (int)sizeof(T);
     const int nk = p.K / KSTEP;
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // The residual tile is fetched BEFORE the K loop into registers, in the epilogue's store layout (its HBM
     // latency would otherwise sit, exposed, between the last MFMA and the stores).
     constexpr bool RPRE = (EPI == EPI_STD && sizeof(OutT) == 4);
-    float4 rpre[RPRE ? 16 : 1];
+    float4 rpre[RPRE ? MI * 4 : 1];
     if constexpr (RPRE) {
         if (p.residual) {
             const int ncol = n0 + wn * 64 + (lane & 15) * 4;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    int mm = m0 + wm * 64 + mi * 16 + it * 4 + (lane >> 4);
+                    int mm = m0 + wm * (MI * 16) + mi * 16 + it * 4 + (lane >> 4);
                     mm = mm < p.M ? mm : p.M - 1;
                     const int nc = ncol < p.N ? ncol : 0;
                     rpre[mi * 4 + it] = *reinterpret_cast<const float4*>(p.residual + (size_t)(mm % p.res_rows) * p.ldr + nc);
@@ -104,14 +110,14 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
         }
     }
 
-    stage_tile<T>(A, p.lda, m0, p.M, 0, lds, wave, lane);
-    stage_tile<T>(W, p.ldw, n0, p.N, 0, lds + TILE_BYTES, wave, lane);
+    stage_tile<T, CH>(A, p.lda, m0, p.M, 0, lds, wave, lane);
+    stage_tile<T, CH>(W, p.ldw, n0, p.N, 0, lds + TILE_BYTES, wave, lane);
 
     // fold coefficients of this lane's rows / columns, requested before the K loop (a small-batch launch has nothing else to
     // hide their latency behind)
     [[maybe_unused]] float4 fcc[FOLD ? 4 : 1], fdd[FOLD ? 4 : 1];
-    [[maybe_unused]] float2 fab[FOLD ? 4 : 1];
-    [[maybe_unused]] float2 fpa[FOLD && STAGES == 4 ? 4 : 1][8], fpb[FOLD && STAGES == 4 ? 4 : 1][8];   // raw partial statistics (in-kernel coefficients)
+    [[maybe_unused]] float2 fab[FOLD ? MI : 1];
+    [[maybe_unused]] float2 fpa[FOLD && STAGES == 4 ? MI : 1][8], fpb[FOLD && STAGES == 4 ? MI : 1][8];   // raw partial statistics (in-kernel coefficients)
     if constexpr (FOLD) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -120,56 +126,70 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
         }
         if (STAGES == 4 && p.ln_parts) {                     // launch-uniform: coefficients from the partial statistics, combined after the K loop
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                ln_coef_row_load(reinterpret_cast<const float2*>(p.ln_parts) + (size_t)(m0 + wm * 64 + mi * 16 + l15) * p.ln_nparts, p.ln_nparts,
+            for (int mi = 0; mi < MI; ++mi)
+                ln_coef_row_load(reinterpret_cast<const float2*>(p.ln_parts) + (size_t)(m0 + wm * (MI * 16) + mi * 16 + l15) * p.ln_nparts, p.ln_nparts,
                                  fpa[mi], fpb[mi]);
         } else {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) fab[mi] = *reinterpret_cast<const float2*>(p.ln_coef + (size_t)(m0 + wm * 64 + mi * 16 + l15) * 2);
+            for (int mi = 0; mi < MI; ++mi) fab[mi] = *reinterpret_cast<const float2*>(p.ln_coef + (size_t)(m0 + wm * (MI * 16) + mi * 16 + l15) * 2);
         }
     }
 
     if constexpr (STAGES == 4) {
         // K-tiles 1 and 2 follow tile 0 at once; tile kt + 3 is requested when tile kt is entered (its stage held tile kt - 1,
         // which every wave has finished reading once it has passed this K-tile's barrier)
-        if (nk > 1) { stage_tile<T>(A, p.lda, m0, p.M, KSTEP, lds + STAGE_BYTES, wave, lane); stage_tile<T>(W, p.ldw, n0, p.N, KSTEP, lds + STAGE_BYTES + TILE_BYTES, wave, lane); }
-        if (nk > 2) { stage_tile<T>(A, p.lda, m0, p.M, 2 * KSTEP, lds + 2 * STAGE_BYTES, wave, lane); stage_tile<T>(W, p.ldw, n0, p.N, 2 * KSTEP, lds + 2 * STAGE_BYTES + TILE_BYTES, wave, lane); }
+        if (nk > 1) { stage_tile<T, CH>(A, p.lda, m0, p.M, KSTEP, lds + STAGE_BYTES, wave, lane); stage_tile<T, CH>(W, p.ldw, n0, p.N, KSTEP, lds + STAGE_BYTES + TILE_BYTES, wave, lane); }
+        if (nk > 2) { stage_tile<T, CH>(A, p.lda, m0, p.M, 2 * KSTEP, lds + 2 * STAGE_BYTES, wave, lane); stage_tile<T, CH>(W, p.ldw, n0, p.N, 2 * KSTEP, lds + 2 * STAGE_BYTES + TILE_BYTES, wave, lane); }
         const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-        // per-lane fragment addresses: row (w * 64 + f * 16 + l15), slot (kk * 4 + g) ^ (row & 7); f steps by an immediate
-        const unsigned fa0 = lds_base + (unsigned)(wm * 64 + l15) * ROWB + (unsigned)(((0 + g) ^ (l15 & 7)) << 4);
-        const unsigned fa1 = lds_base + (unsigned)(wm * 64 + l15) * ROWB + (unsigned)(((4 + g) ^ (l15 & 7)) << 4);
+        // per-lane fragment addresses: row (w * rows + f * 16 + l15), slot (kk * 4 + g) ^ (row & 7); f steps by an immediate
+        const unsigned fa0 = lds_base + (unsigned)(wm * (MI * 16) + l15) * ROWB + (unsigned)(((0 + g) ^ (l15 & 7)) << 4);
+        const unsigned fa1 = lds_base + (unsigned)(wm * (MI * 16) + l15) * ROWB + (unsigned)(((4 + g) ^ (l15 & 7)) << 4);
         const unsigned fw0 = lds_base + TILE_BYTES + (unsigned)(wn * 64 + l15) * ROWB + (unsigned)(((0 + g) ^ (l15 & 7)) << 4);
         const unsigned fw1 = lds_base + TILE_BYTES + (unsigned)(wn * 64 + l15) * ROWB + (unsigned)(((4 + g) ^ (l15 & 7)) << 4);
 #define PM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
         for (int kt = 0; kt < nk; ++kt) {
-            // this wave's 8 DMA instructions of tile kt have landed: at most two younger tiles (16 instructions) stay in flight
+            // this wave's 2 * CH DMA instructions of tile kt have landed: at most two younger tiles stay in flight
             const int younger = min(nk - 1 - kt, 2);
-            if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (CH == 4) {
+                if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
             if (kt + 3 < nk) {
                 unsigned char* nxt = lds + ((kt + 3) & 3) * STAGE_BYTES;
-                stage_tile<T>(A, p.lda, m0, p.M, (kt + 3) * KSTEP, nxt, wave, lane);
-                stage_tile<T>(W, p.ldw, n0, p.N, (kt + 3) * KSTEP, nxt + TILE_BYTES, wave, lane);
+                stage_tile<T, CH>(A, p.lda, m0, p.M, (kt + 3) * KSTEP, nxt, wave, lane);
+                stage_tile<T, CH>(W, p.ldw, n0, p.N, (kt + 3) * KSTEP, nxt + TILE_BYTES, wave, lane);
             }
             const unsigned so = (unsigned)(kt & 3) * STAGE_BYTES;
             typedef unsigned frag_t __attribute__((ext_vector_type(4)));   // (a struct type cannot be a tied asm operand)
-            frag_t af[2][4], wf[2][4];
-            PM_DSR(af[0][0], fa0 + so, 0 * 2048); PM_DSR(af[0][1], fa0 + so, 1 * 2048); PM_DSR(af[0][2], fa0 + so, 2 * 2048); PM_DSR(af[0][3], fa0 + so, 3 * 2048);
+            frag_t af[2][MI], wf[2][4];
+            PM_DSR(af[0][0], fa0 + so, 0 * 2048); PM_DSR(af[0][1], fa0 + so, 1 * 2048);
+            if constexpr (MI == 4) { PM_DSR(af[0][2], fa0 + so, 2 * 2048); PM_DSR(af[0][3], fa0 + so, 3 * 2048); }
             PM_DSR(wf[0][0], fw0 + so, 0 * 2048); PM_DSR(wf[0][1], fw0 + so, 1 * 2048); PM_DSR(wf[0][2], fw0 + so, 2 * 2048); PM_DSR(wf[0][3], fw0 + so, 3 * 2048);
-            PM_DSR(af[1][0], fa1 + so, 0 * 2048); PM_DSR(af[1][1], fa1 + so, 1 * 2048); PM_DSR(af[1][2], fa1 + so, 2 * 2048); PM_DSR(af[1][3], fa1 + so, 3 * 2048);
+            PM_DSR(af[1][0], fa1 + so, 0 * 2048); PM_DSR(af[1][1], fa1 + so, 1 * 2048);
+            if constexpr (MI == 4) { PM_DSR(af[1][2], fa1 + so, 2 * 2048); PM_DSR(af[1][3], fa1 + so, 3 * 2048); }
             PM_DSR(wf[1][0], fw1 + so, 0 * 2048); PM_DSR(wf[1][1], fw1 + so, 1 * 2048); PM_DSR(wf[1][2], fw1 + so, 2 * 2048); PM_DSR(wf[1][3], fw1 + so, 3 * 2048);
-            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(wf[0][0]), "+v"(wf[0][1]),
-                         "+v"(wf[0][2]), "+v"(wf[0][3]));
+            if constexpr (MI == 4)
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(wf[0][0]), "+v"(wf[0][1]),
+                             "+v"(wf[0][2]), "+v"(wf[0][3]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[0][2]), "+v"(wf[0][3]));
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) Mma<T>::run(acc[mi][ni], __builtin_bit_cast(uint4, wf[0][ni]), __builtin_bit_cast(uint4, af[0][mi]));
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]), "+v"(wf[1][0]), "+v"(wf[1][1]),
-                         "+v"(wf[1][2]), "+v"(wf[1][3]));
+            if constexpr (MI == 4)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]), "+v"(wf[1][0]), "+v"(wf[1][1]),
+                             "+v"(wf[1][2]), "+v"(wf[1][3]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[1][2]), "+v"(wf[1][3]));
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) Mma<T>::run(acc[mi][ni], __builtin_bit_cast(uint4, wf[1][ni]), __builtin_bit_cast(uint4, af[1][mi]));
         }
@@ -209,24 +229,24 @@ __global__ __launch_bounds__(THREADS) void gemm_nt_kernel(const GemmParams p) {
     if constexpr (FOLD && STAGES == 4) {
         if (p.ln_parts) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
                 fab[mi] = ln_coef_row(fpa[mi], fpb[mi], p.ln_nparts, p.ln_eps);
-                if (tn == 0 && wn == 0 && g == 0) reinterpret_cast<float2*>(p.ln_coef_out)[(size_t)(m0 + wm * 64 + mi * 16 + l15)] = fab[mi];
+                if (tn == 0 && wn == 0 && g == 0) reinterpret_cast<float2*>(p.ln_coef_out)[(size_t)(m0 + wm * (MI * 16) + mi * 16 + l15)] = fab[mi];
             }
         }
     }
     if constexpr (FOLD) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             const pk2_t xx = pk_splat(fab[mi].x), yy = pk_splat(fab[mi].y);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) ln_apply4(acc[mi][ni], xx, yy, fcc[ni], fdd[ni]);
         }
     }
     if constexpr (EPI == EPI_STD && sizeof(OutT) == 2 && sizeof(T) == 2) {
-        if (p.out_lo) { wave_epilogue<EPI, OutT, 4, 1, false, 2, NoHook, STAGES != 4>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre); return; }   // bf16 hi/lo residual stream
+        if (p.out_lo) { wave_epilogue<EPI, OutT, MI, 1, false, 2, NoHook, STAGES != 4>(p, acc, eraw, m0 + wm * (MI * 16), n0 + wn * 64, lane, rpre); return; }   // bf16 hi/lo residual stream
     }
-    wave_epilogue<EPI, OutT, 4, RPRE ? 16 : 1, false, -1, NoHook, STAGES != 4>(p, acc, eraw, m0 + wm * 64, n0 + wn * 64, lane, rpre);
+    wave_epilogue<EPI, OutT, MI, RPRE ? MI * 4 : 1, false, -1, NoHook, STAGES != 4>(p, acc, eraw, m0 + wm * (MI * 16), n0 + wn * 64, lane, rpre);
 }
 
 int env_int(const char* name, int dflt);
@@ -243,7 +263,9 @@ int launch(const GemmParams& p, hipStream_t s) {
     PmTimer tm(gemm_family(p, EPI), s);
     if constexpr (sizeof(T) == 2) {
         if (deep128(tiles, p.K)) {
-            hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, OutT, FOLD, 4>), dim3(tiles), dim3(THREADS), 0, s, p);
+            // eight waves, except for the head-split epilogue: its V^T transposition works on 64-token blocks (a 64-row wave tile)
+            if constexpr (EPI == EPI_HEADS) hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, OutT, FOLD, 4, 2>), dim3(tiles), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, OutT, FOLD, 4, 4>), dim3(tiles), dim3(512), 0, s, p);
             PM_HIP(hipGetLastError());
             return PMHIP_OK;
         }

@@ -233,6 +233,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
     if (!FULL && nw >= p.N) return;
 
     if constexpr (EPI == EPI_HEADS) {
+        static_assert(MI % 4 == 0, "the head-split epilogue transposes V in 64-token blocks: the wave tile must be a multiple of 64 rows");
         // V part: 64-token x 64-d blocks are transposed through LDS as OutT so that V^T[b,h,d,:] rows are written
         // 128 B (bf16) at a time; Q and K take the generic 16-row path below.
         if (p.kinds[nw / p.inner] == PMHIP_PART_V) {
