@@ -56,3 +56,23 @@ def test_bench_work_accounting_is_consistent():
     kinds = {}
     bench.layer_flops(512, 8, 2048, 1024, False, None, kinds)
     assert kinds["bytes_resid2b"] == 1024 * (512 * 2 + 512 * 8) and kinds["bytes_resid"] == 1024 * (1368 * 2 + 512 * 8)
+
+
+def test_rank_processes_run_eagerly_without_the_polling_helper_thread():
+    """bench.py sets AMD_DIRECT_DISPATCH=0 and drops hipGraph replay for every rank of an N > 1 job before anything loads the HIP
+    runtime (profiles/r05_c_host_polling.txt: 0.12 instead of 1.02 host cores per rank at the same throughput; graph replay is not
+    usable in that runtime mode on ROCm 7.2); a single-GPU run keeps graph replay; PM_BENCH_RANK_GRAPH=1 opts out."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = "import os, bench; print(os.environ.get('AMD_DIRECT_DISPATCH', 'unset'), bench.USE_GRAPH)"
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("AMD_DIRECT_DISPATCH", "WORLD_SIZE", "PM_BENCH_RANK_GRAPH", "PM_BENCH_NO_GRAPH")}
+        e.update(env)
+        return subprocess.run([sys.executable, "-c", probe], cwd=root, env=e, capture_output=True, text=True, timeout=120).stdout.split()
+
+    assert run() == ["unset", "True"]
+    assert run(WORLD_SIZE="8") == ["0", "False"]
+    assert run(WORLD_SIZE="8", PM_BENCH_RANK_GRAPH="1") == ["unset", "True"]
+    assert run(AMD_DIRECT_DISPATCH="0") == ["0", "False"]           # whoever sets the mode gets the eager loop
