@@ -778,12 +778,17 @@ def main():
     img_px = stage1_cfg(cfg0)["enc"]["image_size"]
 
     recv = {}                                    # rank 0: receive buffers per (lane, shape), allocated once
-    inflight = []                                # (work handle, tensor) of gathers not yet waited for
+    gather_streams = {}                          # lane -> the side stream its gathers are issued from
+    inflight = []                                # tensors handed to a gather that has not been drained yet (kept alive)
 
     def gather(last, lane=0, asynchronous=False):
         """the path's only collective: finished images -> rank 0.  RCCL runs it on the process group's own stream, ordered
-        after the calling stream's work so far.  asynchronous: the calling stream does NOT wait for the collective (the lane
-        goes straight on with its next replay); the handle is waited for once, before the closing synchronize."""
+        after the calling stream's work so far.  `asynchronous` (the free-running lane loop): issued from the lane's own stream
+        with the ordinary synchronous-API call, i.e. the LANE waits for the collective on the device (well under a millisecond
+        per 134 ms step) and no host thread waits at all.  The two alternatives were measured with one RCCL rank in the rank
+        mode above (profiles/r05_c_host_polling.txt, PM_BENCH_GATHER_MODE): `async_op=True` handles cost a thread spinning at a
+        full core from the first use until the group is destroyed (1.12 cores per rank), a side stream per lane two (2.13);
+        the plain call 0.12."""
         if dist is None:
             return last
         bufs = None
@@ -792,8 +797,18 @@ def main():
             if key not in recv:
                 recv[key] = [torch.empty_like(last) for _ in range(world)]
             bufs = recv[key]
-        if asynchronous:
+        mode = os.environ.get("PM_BENCH_GATHER_MODE", "lane")       # lane | side | async  (development A/B)
+        if asynchronous and mode == "async":
             inflight.append((dist.gather(last, bufs, dst=0, async_op=True), last))
+        elif asynchronous and mode == "side":
+            side = gather_streams.get(lane)
+            if side is None:
+                side = gather_streams[lane] = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                dist.gather(last, bufs, dst=0)
+            last.record_stream(side)
+            inflight.append(last)
         else:
             dist.gather(last, bufs, dst=0)
         return last
@@ -806,8 +821,11 @@ def main():
                 gather(imgs[-1], lane, asynchronous=True)
 
     def drain_gathers():
-        for work, _ in inflight:
-            work.wait()
+        for side in gather_streams.values():
+            side.synchronize()
+        for it in inflight:
+            if isinstance(it, tuple):
+                it[0].wait()
         inflight.clear()
 
     # one-time setup, not a benchmark step: the first two calls size the workspaces and capture the decode-loop

@@ -332,3 +332,24 @@ def test_centred_hi_plane_keeps_the_fold_accurate_on_offset_rows(monkeypatch):
     print(f"rows of offset 30: bf16 vs fp32 logits (max err, mean err, top-1 agreement): centred {err['1']}, not centred {err['0']}")
     assert err["1"][0] < BF16_LOGIT_MAXERR * 2 and err["1"][1] < BF16_LOGIT_MEANERR * 2
     assert err["1"][1] < 0.6 * err["0"][1]
+
+
+def test_small_batches_run_small_batch_kernels_and_give_the_large_batch_bits(pipe512):
+    """Round 5: one or two images take small-batch forms of every hot kernel (64 / 128-query attention workgroups, the folded
+    LayerNorm on the four-stage 128x128 GEMM with its coefficients computed in the prologue, eight-wave producers) and the
+    graph-replayed loop defers each step's ViT decode to a side stream beside the next step's tower.  None of that may change
+    a bit: the sampling noise is keyed by the global image index, so images 0 / 0-1 / 0-4 of a 40-image batch (large-batch
+    kernels, no deferred decode) must equal the same images generated alone -- ids and every decoded image, bf16 mode, eager
+    and graph replay (reference generate.py:183-198 has one code path and no batch dependence)."""
+    pipe = pipe512
+    pipe.set_compute_dtype(torch.bfloat16)
+    try:
+        T, flags = 4, [True] * 4
+        ids40, imgs40 = pipe.generate_ids(None, 40, T, 1.0, 5, flags, seed=321, use_graph=False, streams=1)
+        for nb in (1, 2, 5):
+            for rep, graph in enumerate((False, True, True, True)):          # eager; graph: eager warm-up, capture, replay
+                ids, imgs = pipe.generate_ids(None, nb, T, 1.0, 5, flags, seed=321, use_graph=graph, streams=1)
+                assert torch.equal(ids, ids40[:nb]), (nb, rep)
+                assert torch.equal(imgs, imgs40[:, :nb]), (nb, rep)
+    finally:
+        pipe.set_compute_dtype(torch.float32)
