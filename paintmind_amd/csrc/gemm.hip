@@ -60,7 +60,7 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ base, int ld, i
 // order per output element is unchanged (K-tiles in order, k-halves in order): same bits as STAGES = 2 and as gemm256.hip.
 // WM = waves along m (x 2 along n).  WM = 4 (the latency form only): EIGHT waves, two per SIMD, each 32 x 64 of the tile: a wave
 // issues half of the LDS-DMA instructions per K-tile (with four waves a K-tile cost 0.57 us for 0.23 us of MFMA) and its SIMD
-// partner computes meanwhile.
+// partner computes meanwhile (the head-split epilogue then transposes V^T in 32-token blocks, gemm_common.h).
 template <typename T, int EPI, typename OutT, bool FOLD = false, int STAGES = 2, int WM = 2>
 __global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const GemmParams p) {
     static_assert(STAGES == 2 || (STAGES == 4 && sizeof(T) == 2), "the four-stage K loop is the bf16 small-batch form");
@@ -263,9 +263,7 @@ int launch(const GemmParams& p, hipStream_t s) {
     PmTimer tm(gemm_family(p, EPI), s);
     if constexpr (sizeof(T) == 2) {
         if (deep128(tiles, p.K)) {
-            // eight waves, except for the head-split epilogue: its V^T transposition works on 64-token blocks (a 64-row wave tile)
-            if constexpr (EPI == EPI_HEADS) hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, OutT, FOLD, 4, 2>), dim3(tiles), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, OutT, FOLD, 4, 4>), dim3(tiles), dim3(512), 0, s, p);
+            hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, OutT, FOLD, 4, 4>), dim3(tiles), dim3(512), 0, s, p);
             PM_HIP(hipGetLastError());
             return PMHIP_OK;
         }

@@ -233,43 +233,47 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
     if (!FULL && nw >= p.N) return;
 
     if constexpr (EPI == EPI_HEADS) {
-        static_assert(MI % 4 == 0, "the head-split epilogue transposes V in 64-token blocks: the wave tile must be a multiple of 64 rows");
-        // V part: 64-token x 64-d blocks are transposed through LDS as OutT so that V^T[b,h,d,:] rows are written
-        // 128 B (bf16) at a time; Q and K take the generic 16-row path below.
+        // V part: TB-token x 64-d blocks (TB = 64; 32 for the 32-row wave tiles of the eight-wave small-batch GEMM) are transposed
+        // through LDS as OutT so that V^T[b,h,d,:] rows are written 128 B / 64 B (bf16) at a time; Q and K take the generic
+        // 16-row path below.
+        static_assert(MI % 4 == 0 || MI == 2, "the head-split epilogue transposes V in blocks of 64 (or 32) tokens");
         if (p.kinds[nw / p.inner] == PMHIP_PART_V) {
             hook();
+            constexpr int TB = MI >= 4 ? 64 : MI * 16;                         // tokens per transposed block
+            constexpr int MIB = TB / 16;                                         // accumulator row tiles per block
+            constexpr int LPRV = TB / 8, RPIV = 64 / LPRV, ITV = 64 / RPIV;      // 16-byte lanes per d-row, d-rows per store, stores
             const int h = (nw % p.inner) >> 6;
             OutT* dst = reinterpret_cast<OutT*>(p.outs[nw / p.inner]);
 #pragma unroll
-            for (int blk = 0; blk < MI / 4; ++blk) {
-                const int mblk = mwave + blk * 64;
+            for (int blk = 0; blk < MI / MIB; ++blk) {
+                const int mblk = mwave + blk * TB;
                 const int b0 = mblk / p.tokens, t0 = mblk % p.tokens;
-                const bool whole = (FULL || mblk + 63 < p.M) && (t0 + 63 < p.tokens) && (t0 % 8 == 0);
+                const bool whole = (FULL || mblk + TB - 1 < p.M) && (t0 + TB - 1 < p.tokens) && (t0 % 8 == 0);
                 if (whole && sizeof(OutT) == 2) {
-                    OutT* vbuf = reinterpret_cast<OutT*>(eraw);                  // [64 d][64 tokens]
+                    OutT* vbuf = reinterpret_cast<OutT*>(eraw);                  // [64 d][TB tokens]
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
+                    for (int mi = 0; mi < MIB; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                vbuf[(ni * 16 + g * 4 + r) * 64 + mi * 16 + l15] = from_f32<OutT>(acc[blk * 4 + mi][ni][r]);
+                                vbuf[(ni * 16 + g * 4 + r) * TB + mi * 16 + l15] = from_f32<OutT>(acc[blk * MIB + mi][ni][r]);
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     // one per-lane base on each side + wave-uniform steps: eight separate row indices kept live across the
                     // whole kernel cost the folded head-split variant two spills, reloaded here behind a vmcnt(0) that drained
                     // the next tile's DMA (+24 us per launch)
-                    OutT* vptr = dst + (((size_t)b0 * p.heads + h) * 64 + (lane >> 3)) * p.tokens_pad + t0 + (lane & 7) * 8;
-                    const unsigned char* lptr = eraw + (lane >> 3) * 128 + (lane & 7) * 16;
-                    const size_t vstep = (size_t)8 * p.tokens_pad;
+                    OutT* vptr = dst + (((size_t)b0 * p.heads + h) * 64 + (lane / LPRV)) * p.tokens_pad + t0 + (lane % LPRV) * 8;
+                    const unsigned char* lptr = eraw + (lane / LPRV) * (TB * 2) + (lane % LPRV) * 16;
+                    const size_t vstep = (size_t)RPIV * p.tokens_pad;
 #pragma unroll
-                    for (int it = 0; it < 8; ++it)                               // 8 d-rows x 128 B per store instruction
-                        st16<NT>(vptr + it * vstep, *reinterpret_cast<const uint4*>(lptr + it * 1024));
+                    for (int it = 0; it < ITV; ++it)                             // RPIV d-rows x TB*2 bytes per store instruction
+                        st16<NT>(vptr + it * vstep, *reinterpret_cast<const uint4*>(lptr + it * (RPIV * TB * 2)));
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 } else {
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) {
+                    for (int mi = 0; mi < MIB; ++mi) {
                         const int mm = mblk + mi * 16 + l15;
                         if (mm < p.M) {
                             const int b = mm / p.tokens, t = mm % p.tokens;
@@ -278,7 +282,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
 #pragma unroll
                                 for (int r = 0; r < 4; ++r)
                                     dst[(((size_t)b * p.heads + h) * 64 + ni * 16 + g * 4 + r) * p.tokens_pad + t] =
-                                        from_f32<OutT>(acc[blk * 4 + mi][ni][r]);
+                                        from_f32<OutT>(acc[blk * MIB + mi][ni][r]);
                         }
                     }
                 }
