@@ -73,6 +73,9 @@ constexpr int DH = 64;
 constexpr int THREADS = 256;
 constexpr int TILE_BYTES = KT * 128;
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;              // K tile + V^T tile
+#ifndef PM_ATTN_KSWZ
+#define PM_ATTN_KSWZ 1        // 0: the K tile swizzle of rounds 3-4 (2-way bank conflicts on the K fragment reads); A/B only
+#endif
 #ifndef PM_ATTN_RING
 #define PM_ATTN_RING 4
 #endif
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
     // DMA descriptors / lane offsets, and the per-lane parts of the fragment addresses (ds_read_b128 with immediate offsets)
     //   K row of S^T tile kf = 2 pc + kk, row i = l15:  32 pc + 8 (l15 >> 2) + 4 kk + (l15 & 3);  slot (4 c + g) ^ (row & 7)
     //     = stage + [8 (l15 >> 2) + (l15 & 3)] * 128 + (g ^ (l15 & 3)) * 16  +  pc * 4096 + kk * 512 + (c ^ kk) * 64
+    //     (round 5: slot additionally ^ 4 where bit 3 of the row is set, i.e. "+ (c ^ kk ^ ((l15 >> 2) & 1)) * 64")
     //   V^T row 16 df + l15, slot (4 pc + g) ^ (l15 & 7)
     //     = stage + 8192 + l15 * 128 + ((4 pc + g) ^ (l15 & 7)) * 16  +  df * 2048
     const rsrc_t Kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Kbh), 0, 0x7fffffff, 0x00020000);
@@ -142,8 +146,15 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const unsigned lslot = (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
     const unsigned kvoff = (unsigned)(lane >> 3) * 128u + lslot;
+    // K tile, bank conflicts (round 5): a ds_read_b128 is served 16 lanes at a time ({0-3, 12-15, 20-27}, ...), and the S^T row
+    // order puts l15 = 0..3 and 12..15 on rows 0..3 and 24..27 -- same row & 7, same slot: a 2-way conflict on every K fragment
+    // read (SQ_LDS_BANK_CONFLICT a third of SQ_LDS_IDX_ACTIVE).  Bit 3 of the row now flips bit 2 of the slot as well: the odd
+    // 8-row chunks are DMA'd with the flipped source slot, and the read side flips it for the lanes with (l15 >> 2) odd.
+    const unsigned kvoff1 = PM_ATTN_KSWZ ? kvoff ^ 64u : kvoff;
     const unsigned vvoff = (unsigned)(lane >> 3) * v_row_bytes + lslot;
-    const unsigned kfrag_lane = lds_base + (unsigned)(8 * (l15 >> 2) + (l15 & 3)) * 128u + (unsigned)((g ^ (l15 & 3)) << 4);
+    const unsigned kfrag_lane = lds_base + (unsigned)(8 * (l15 >> 2) + (l15 & 3)) * 128u + (unsigned)((g ^ (l15 & 3)) << 4) +
+                                (PM_ATTN_KSWZ ? (unsigned)(((l15 >> 2) & 1) << 6) : 0u);          // slots with c ^ kk = 0
+    const unsigned kfrag_laneB = kfrag_lane ^ 64u;                                                 // slots with c ^ kk = 1
     const unsigned vfrag_lane0 = lds_base + 8192u + (unsigned)l15 * 128u + (unsigned)(((0 + g) ^ (l15 & 7)) << 4);
     const unsigned vfrag_lane1 = lds_base + 8192u + (unsigned)l15 * 128u + (unsigned)(((4 + g) ^ (l15 & 7)) << 4);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned chunk = (unsigned)wave_u * 2 + i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Kr, (__attribute__((address_space(3))) void*)(stage + chunk * 1024), 16, kvoff,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Kr, (__attribute__((address_space(3))) void*)(stage + chunk * 1024), 16, i ? kvoff1 : kvoff,
                                                      (kv0 + chunk * 8) * 128u, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(Vr, (__attribute__((address_space(3))) void*)(stage + KT * 128 + chunk * 1024), 16, vvoff,
                                                      chunk * 8 * v_row_bytes + kv0 * 2u, 0, 0);
@@ -188,9 +199,10 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
     const int nhalves = (Nkv + 31) / 32;                     // 32-key half-tiles that contain at least one valid key
 
     auto k_issue = [&](v4u_t (&kf)[2][2], int hh) {
-        const unsigned ka = kfrag_lane + (unsigned)((hh >> 1) % RING) * STAGE_BYTES + (unsigned)(hh & 1) * 4096u;
-        DSRX(kf[0][0], ka, 0 * 512 + 0 * 64); DSRX(kf[0][1], ka, 0 * 512 + 1 * 64);
-        DSRX(kf[1][0], ka, 1 * 512 + 1 * 64); DSRX(kf[1][1], ka, 1 * 512 + 0 * 64);
+        const unsigned so = (unsigned)((hh >> 1) % RING) * STAGE_BYTES + (unsigned)(hh & 1) * 4096u;
+        const unsigned ka = kfrag_lane + so, kb = kfrag_laneB + so;
+        DSRX(kf[0][0], ka, 0 * 512); DSRX(kf[0][1], kb, 0 * 512);
+        DSRX(kf[1][0], kb, 1 * 512); DSRX(kf[1][1], ka, 1 * 512);
     };
     auto v_issue = [&](v4u_t (&vf)[4], int hh) {
         const unsigned va = ((hh & 1) ? vfrag_lane1 : vfrag_lane0) + (unsigned)((hh >> 1) % RING) * STAGE_BYTES;
@@ -346,7 +358,8 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
     auto step = [&](auto opens_c, f32x4_t (&sc)[2][QF], int hh) {
         constexpr bool OPENS = decltype(opens_c)::value;
         const unsigned va = (((hh + 1) & 1) ? vfrag_lane1 : vfrag_lane0) + (unsigned)(((hh + 1) >> 1) % RING) * STAGE_BYTES;
-        const unsigned ka = kfrag_lane + (unsigned)(((hh + 2) >> 1) % RING) * STAGE_BYTES + (unsigned)(hh & 1) * 4096u;
+        const unsigned kso = (unsigned)(((hh + 2) >> 1) % RING) * STAGE_BYTES + (unsigned)(hh & 1) * 4096u;
+        const unsigned ka = kfrag_lane + kso, kb = kfrag_laneB + kso;
 #pragma unroll
         for (int g = 0; g < QF; ++g) {
             const bool last = g == QF - 1;
@@ -355,8 +368,8 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
             grp_mma(sc, g);
             if (last) {                                       // the fragment registers are handed over to the next half-tile as they die
                 __builtin_amdgcn_sched_barrier(0);
-                DSRX(kf[0][0], ka, 0 * 512 + 0 * 64); DSRX(kf[0][1], ka, 0 * 512 + 1 * 64);
-                DSRX(kf[1][0], ka, 1 * 512 + 1 * 64); DSRX(kf[1][1], ka, 1 * 512 + 0 * 64);
+                DSRX(kf[0][0], ka, 0 * 512); DSRX(kf[0][1], kb, 0 * 512);
+                DSRX(kf[1][0], kb, 1 * 512); DSRX(kf[1][1], ka, 1 * 512);
             }
             if (g == 0) {
                 if (last) LGKM4(4, vf[0], vf[1], vf[2], vf[3]);                     // (QF = 1: the K(h+2) reads just issued stay in flight)

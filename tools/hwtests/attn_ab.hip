@@ -35,6 +35,11 @@ namespace g4_qf1 {
 #include "../../paintmind_amd/csrc/attention_bf16.hip"
 }
 #undef PM_ATTN_FORCE_QF
+#define PM_ATTN_KSWZ 0
+namespace g4_kswz0 {
+#include "../../paintmind_amd/csrc/attention_bf16.hip"
+}
+#undef PM_ATTN_KSWZ
 #define PM_ATTN_RING 3
 namespace g4_ring3 {
 #include "../../paintmind_amd/csrc/attention_bf16.hip"
@@ -90,6 +95,7 @@ int main(int argc, char** argv) {
     V vs[] = {{"gen3 (round 4)", gen3::pm_attention_bf16, true, 0}, {"gen4", gen4::pm_attention_bf16, true, 0},
               {"gen4 256 queries / WG", g4_qf4::pm_attention_bf16, true, 0}, {"gen4 128 queries / WG", g4_qf2::pm_attention_bf16, true, 0},
               {"gen4  64 queries / WG", g4_qf1::pm_attention_bf16, true, 0},
+              {"gen4 old K swizzle", g4_kswz0::pm_attention_bf16, true, 0},
               {"gen4 3-stage ring", g4_ring3::pm_attention_bf16, true, 0},
               {"gen4 no exp (mul)", g4_noexp::pm_attention_bf16, false, 0}, {"gen4 no fragment reads", g4_noreads::pm_attention_bf16, false, 0},
               {"gen4 no DMA", g4_nodma::pm_attention_bf16, false, 0}, {"gen4 no barrier", g4_nobarrier::pm_attention_bf16, false, 0},
