@@ -1,9 +1,11 @@
-// Fused softmax(Q K^T) V in bf16 for dim_head = 64 (gfx950), third generation.
+// Fused softmax(Q K^T) V in bf16 for dim_head = 64 (gfx950), fourth generation (the third-generation notes are kept below
+// because the fourth builds on them).
 // Replaces the reference's materialised-score attention (modules/attention.py:51-58: q@k^T -> softmax -> @v, a
 // (B*H, N, N) fp32 tensor per layer) and its xformers alternative (:100).  Same data layout and work split as the
 // f32 kernel in attention.hip (which stays the fp32-verify path): Q [B,H,Nq,64] pre-scaled, K [B,H,Np,64],
-// V^T [B,H,64,Np]; one workgroup = 256 queries of one (batch, head), 4 waves x 64 queries; K / V^T tiles of 64 keys
-// by DMA into a 3-stage LDS ring, one barrier per tile; swapped QK^T (a lane owns 8 consecutive keys of ONE query per
+// V^T [B,H,64,Np]; one workgroup = 64*QF queries of one (batch, head), 4 waves x 16*QF queries (QF = 4, or 2 / 1 when the
+// launch would otherwise leave CUs idle: bit-identical forms); K / V^T tiles of 64 keys by DMA into a 4-stage LDS ring with
+// counted vmcnt waits, one bare s_barrier per tile; swapped QK^T (a lane owns 8 consecutive keys of ONE query per
 // 32-key half-tile, so P feeds the P.V product straight from the S^T accumulators).
 //
 // What changed against the second generation (round 2: 0.40 MFMA busy, 4.5 VALU per MFMA):
@@ -104,6 +106,10 @@ __device__ __forceinline__ f32x4_t mma(const v4u_t& rows, const v4u_t& cols, con
 // workgroups of 41 us each).  The arithmetic of a 16-query tile does not depend on QF or on its neighbours in the workgroup
 // (same MFMA chains, same half-tile order, the fallback below decided per tile), so an image's result does not depend on the
 // batch it runs in.
+// (Measured and not adopted, round 5: ONE workgroup of 8 waves / 512 queries per CU sharing the ring -- half the DMA pieces per
+// wave and per CU -- needs 13 % MORE cycles, 2.45e6 against 2.16e6 per launch, MFMA busy 0.49 against 0.55: the 8-wave barrier
+// per tile costs more than the DMA saves; two independent 4-wave workgroups cover each other's barrier waits.  The patch is
+// tools/ab_variants/attn_wv8.patch, the numbers profiles/r05_a_attention_gen4_ab.txt (5).)
 template <bool EXP2, int QF>
 __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
                                                                     const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
