@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PMHIP_ABI_VERSION 9
+#define PMHIP_ABI_VERSION 10
 
 enum { PMHIP_OK = 0, PMHIP_EINVAL = 1, PMHIP_EHIP = 2, PMHIP_ENOMEM = 3, PMHIP_ESTATE = 4 };
 enum { PMHIP_F32 = 0, PMHIP_BF16 = 1 };
@@ -146,6 +146,13 @@ int pmhip_gemm_heads_ln(int dtype, const void* A, int lda, const void* W, int ld
                         pmhip_stream stream);
 int pmhip_lnfold_supported(int dtype, int epi_kind, int M, int N, int K);
 
+/* The logits GEMM of the MaskGIT step (stage2/transformer.py:91: to_logits) with the sampler's statistics from its epilogue (round 5):
+ * out (f32) [M,N] = A . W^T + bias -- A, W as for pmhip_gemm, or, with `ln` not NULL, as for pmhip_gemm_ln -- and block_stats
+ * [M][N/64][2] = (max, sum_j 2^((x_j - max) log2 e)) of every 64-column block of every row, computed from the values as they are
+ * stored.  pmhip_sample_rows_stats then needs 8 bytes per block and the top-k blocks of a row instead of the row.  N % 64 == 0. */
+int pmhip_gemm_softmax_stats(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, float* out, int ldo,
+                             int M, int N, int K, const pmhip_lnfold* ln, float* block_stats, pmhip_stream stream);
+
 /* softmax(Q K^T) V per (batch, head), no mask, no dropout (modules/attention.py:51-58; the same
  * maths as xformers.ops.memory_efficient_attention at :100).  Q is already scaled.  Layouts as
  * written by pmhip_gemm_heads.  out[B*Nq, heads*64] (`dtype`), head-major inside a row
@@ -205,6 +212,10 @@ int pmhip_add_rows(const float* x, const float* table, int table_rows, float* ou
  * the text 10 % of the time (utils/trainer.py:379,387-388: `text = None` -> attn2 becomes a second self-attention,
  * modules/attention.py:47) but its own sampling (generate.py:159-181) never combines the two; SURVEY.md section 8(f) row 2. */
 int pmhip_guidance_combine(const float* cond, const float* uncond, float scale, float* out, size_t n, pmhip_stream stream);
+/* The same, and block_stats [n/64][2] = the softmax statistics (max, sum of exp) of every 64-element block of the result, for
+ * pmhip_sample_rows_stats: rows must be contiguous and a multiple of 64 long (n % 64 == 0). */
+int pmhip_guidance_combine_stats(const float* cond, const float* uncond, float scale, float* out, size_t n, float* block_stats,
+                                 pmhip_stream stream);
 
 /* Row gather out[m,:] = table[ids[m],:] (nn.Embedding: stage1/quantize.py:41, generate.py:148-157),
  * table fp32 [V,E], ids int64, out `out_dtype` [M,Kpad] zero-padded. */
@@ -254,6 +265,18 @@ int pmhip_sample_rows(const float* logits, int ldl, const int64_t* ids_in, int64
                       int topk, float temperature, const float* noise, uint64_t seed,
                       uint32_t step, uint64_t row_base, int64_t* pred_out, int64_t* ids_out,
                       float* score_out, int M, int V, pmhip_stream stream);
+
+/* The same step for a caller that holds the SOFTMAX STATISTICS of the rows' 64-column blocks (round 5): block_stats [M][V/64][2] =
+ * (max, sum_j 2^((x_j - max) log2 e)) per block, as pmhip_gemm_softmax_stats / pmhip_guidance_combine_stats leave them behind.
+ * For topk <= 8 the kernel reads the statistics (8 bytes per block) and the topk blocks with the largest maxima -- they contain
+ * the topk largest elements -- instead of the whole row: 1 KiB + topk x 256 B instead of 32 KiB at V = 8192.
+ * Same result, bit for bit, as pmhip_sample_rows on the same logits: for topk <= 8 and V % 64 == 0 that entry runs the same
+ * kernel and derives the statistics from the stored row with the same arithmetic.  (topk > 8: the statistics are ignored.)
+ * V % 64 == 0.  Reference: generate.py:163-173, as above. */
+int pmhip_sample_rows_stats(const float* logits, int ldl, const float* block_stats, const int64_t* ids_in, int64_t mask_id,
+                            int topk, float temperature, const float* noise, uint64_t seed, uint32_t step,
+                            uint64_t row_base, int64_t* pred_out, int64_t* ids_out, float* score_out, int M, int V,
+                            pmhip_stream stream);
 
 /* Re-mask the num_mask least confident tokens of every image (generate.py:175-179):
  * ids[b, topk(scores[b], num_mask)] = mask_id.  Ties: (score desc, index asc). N <= 4096. */

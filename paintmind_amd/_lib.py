@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpaintmind_hip.so")
 PMHIP_OK = 0
 F32, BF16 = 0, 1
 PART_Q, PART_K, PART_V = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 vp = C.c_void_p
 i32 = C.c_int
@@ -84,6 +84,7 @@ PROTOTYPES = {
     "pmhip_join_hilo": (i32, [vp, vp, vp, i32, i32, vp]),
     "pmhip_ln_coef": (i32, [vp, f32, vp, i32, i32, vp]),
     "pmhip_gemm_ln": (i32, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, C.POINTER(LnFold), vp]),
+    "pmhip_gemm_softmax_stats": (i32, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, C.POINTER(LnFold), vp, vp]),
     "pmhip_gemm_swiglu_ln": (i32, [i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, C.POINTER(LnFold), vp]),
     "pmhip_gemm_heads_ln": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32),
                                   C.POINTER(vp), f32, C.POINTER(LnFold), vp]),
@@ -99,6 +100,7 @@ PROTOTYPES = {
     "pmhip_convert_pad": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "pmhip_add_rows": (i32, [vp, vp, i32, vp, i32, i32, vp]),
     "pmhip_guidance_combine": (i32, [vp, vp, C.c_float, vp, C.c_size_t, vp]),
+    "pmhip_guidance_combine_stats": (i32, [vp, vp, C.c_float, vp, C.c_size_t, vp, vp]),
     "pmhip_embed_rows": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "pmhip_random_mask": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]),
     "pmhip_masked_ce": (i32, [vp, i32, vp, vp, f32, vp, vp, i32, i32, vp]),
@@ -106,6 +108,7 @@ PROTOTYPES = {
     "pmhip_vq_scratch_bytes": (C.c_size_t, [i32, i32]),
     "pmhip_vq_quantize": (i32, [vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "pmhip_sample_rows": (i32, [vp, i32, vp, i64, i32, f32, vp, u64, u32, u64, vp, vp, vp, i32, i32, vp]),
+    "pmhip_sample_rows_stats": (i32, [vp, i32, vp, vp, i64, i32, f32, vp, u64, u32, u64, vp, vp, vp, i32, i32, vp]),
     "pmhip_remask": (i32, [vp, vp, i32, i64, i32, i32, vp]),
     "pmhip_vqgan_create": (i32, [C.POINTER(vp), i32, i32, C.POINTER(VqganCfg), C.POINTER(VqganWeights)]),
     "pmhip_vqgan_destroy": (None, [vp]),

@@ -72,9 +72,10 @@ struct PmGenParams {
     float temps[PM_MAX_STEPS];
     int nmask[PM_MAX_STEPS];
 };
-int pm_sample_rows(const float* logits, int ldl, const int64_t* ids_in, int64_t mask_id, int topk, float temperature,
-                   const float* noise, uint64_t seed, uint32_t step, uint64_t row_base, int64_t* pred_out, int64_t* ids_out,
-                   float* score_out, int M, int V, const PmGenParams* gp, pmhip_stream stream);
+// block_stats: NULL, or the (max, sum of exp) pairs of the row's 64-column blocks, [M][V/64][2] (softmax_block_stat below)
+int pm_sample_rows(const float* logits, int ldl, const float* block_stats, const int64_t* ids_in, int64_t mask_id, int topk,
+                   float temperature, const float* noise, uint64_t seed, uint32_t step, uint64_t row_base, int64_t* pred_out,
+                   int64_t* ids_out, float* score_out, int M, int V, const PmGenParams* gp, pmhip_stream stream);
 int pm_remask(int64_t* ids, const float* scores, int num_mask, int64_t mask_id, int B, int N, const PmGenParams* gp, int step,
               pmhip_stream stream);
 
@@ -283,6 +284,31 @@ __device__ __forceinline__ float2 ln_coef_row(const float2 (&pa)[8], const float
     for (int j = 0; j < 8; ++j)
         mv[j] = __fadd_rn(j < nparts ? lnp_m2_term(pa[j], mean) : 0.f, j + 8 < nparts ? lnp_m2_term(pb[j], mean) : 0.f);
     return lnp_finish(lnp_tree8(mv), mean, nparts, eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Softmax statistics of one 64-column block of a logits row: (m, s) = (max, sum_j 2^((x_j - m) log2 e)).  ONE definition of
+// the arithmetic -- explicitly rounded operations in a fixed tree -- shared by the f32 GEMM epilogue (gemm_common.h: the block is
+// the 64 columns a wave owns, at the point where it stores them), the guidance combination (rowops.hip) and the sampling kernel
+// when it has to derive them from a stored row (sample.hip): the same logits give the same bits whoever computes them, so a
+// step's result does not depend on which kernel produced the statistics.
+//   layout: the 16 lanes of a DPP row, lane j holding columns 4j .. 4j+3; every lane of the row returns the block's pair
+// ------------------------------------------------------------------------------------------------
+constexpr float PM_LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float2 softmax_block_stat(float a, float b, float c, float d) {
+    float m = fmaxf(fmaxf(a, b), fmaxf(c, d));
+    m = fmaxf(m, dpp_mov<0xB1>(m));
+    m = fmaxf(m, dpp_mov<0x4E>(m));
+    m = fmaxf(m, dpp_mov<0x141>(m));
+    m = fmaxf(m, dpp_mov<0x140>(m));
+    const float nm = __fmul_rn(m, -PM_LOG2E);
+    float s = __fadd_rn(__fadd_rn(__builtin_amdgcn_exp2f(__fmaf_rn(a, PM_LOG2E, nm)), __builtin_amdgcn_exp2f(__fmaf_rn(b, PM_LOG2E, nm))),
+                        __fadd_rn(__builtin_amdgcn_exp2f(__fmaf_rn(c, PM_LOG2E, nm)), __builtin_amdgcn_exp2f(__fmaf_rn(d, PM_LOG2E, nm))));
+    s = __fadd_rn(s, dpp_mov<0xB1>(s));
+    s = __fadd_rn(s, dpp_mov<0x4E>(s));
+    s = __fadd_rn(s, dpp_mov<0x141>(s));
+    s = __fadd_rn(s, dpp_mov<0x140>(s));
+    return make_float2(m, s);
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

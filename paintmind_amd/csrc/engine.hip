@@ -761,7 +761,9 @@ int s2_prepare_context(pmhip_s2* h, const float* context, int L, int B, hipStrea
 // token rows (T [M,64]) -> logits fp32 [M,V]  (transformer.py:81-82,87-91)
 // use_cross = false: the unconditional branch (context None: every attn2 is a second self-attention, attention.py:47) although a
 // context has been prepared -- the second forward of a guided step
-int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s, bool use_cross = true) {
+// block_stats (optional, n_embed % 64 == 0): the softmax statistics of the logits' 64-column blocks, [M][n_embed/64][2], written by
+// the logits GEMM's epilogue for the sampling kernel (gemm_common.h GemmParams::block_stats)
+int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s, bool use_cross = true, float* block_stats = nullptr) {
     const auto& c = h->cfg;
     const int M = B * c.tokens, dim = c.tower.dim;
     TowerBufs tb;
@@ -776,12 +778,20 @@ int s2_tower(pmhip_s2* h, const void* tp, int B, float* logits, hipStream_t s, b
         const int step = fold_rows(tb, M, c.tokens, dim);
         for (int m0 = 0; m0 < M; m0 += step) {
             const pmhip_lnfold ln = fold_desc(tb, m0, dim, h->w.logits_c, h->w.logits_d);   // the final norm folded into to_logits
-            PM_TRY(pmhip_gemm_ln(h->dtype, reinterpret_cast<const unsigned char*>(tb.xh) + (size_t)m0 * dim * 2, dim, h->w.logits_wf, dim,
-                                 h->w.logits_b, logits + (size_t)m0 * c.n_embed, c.n_embed, PMHIP_F32, std::min(step, M - m0), c.n_embed, dim, &ln, s));
+            const void* a = reinterpret_cast<const unsigned char*>(tb.xh) + (size_t)m0 * dim * 2;
+            if (block_stats)
+                PM_TRY(pmhip_gemm_softmax_stats(h->dtype, a, dim, h->w.logits_wf, dim, h->w.logits_b, logits + (size_t)m0 * c.n_embed, c.n_embed,
+                                                std::min(step, M - m0), c.n_embed, dim, &ln, block_stats + (size_t)m0 * (c.n_embed / 64) * 2, s));
+            else
+                PM_TRY(pmhip_gemm_ln(h->dtype, a, dim, h->w.logits_wf, dim, h->w.logits_b, logits + (size_t)m0 * c.n_embed, c.n_embed, PMHIP_F32,
+                                     std::min(step, M - m0), c.n_embed, dim, &ln, s));
         }
         return PMHIP_OK;
     }
     PM_TRY(tower_layernorm(h->dtype, tb, h->w.norm_g, h->w.norm_b, M, dim, s));
+    if (block_stats)
+        return pmhip_gemm_softmax_stats(h->dtype, tb.y, dim, h->w.logits_w, dim, h->w.logits_b, logits, c.n_embed, M, c.n_embed, dim, nullptr,
+                                        block_stats, s);
     return pmhip_gemm(h->dtype, tb.y, dim, h->w.logits_w, dim, h->w.logits_b, nullptr, 0, 0, logits, c.n_embed, PMHIP_F32, M,
                       c.n_embed, dim, s);
 }
@@ -800,12 +810,17 @@ int step_tower(pmhip_s2* s2, const int64_t* ids, int B, hipStream_t s, const flo
     WS(s2->ws, "s2.logits", (size_t)M * c.n_embed * 4, logits);
     // ids2tokens: lookup in cat(raw codebook, mask_token) (generate.py:148-157)
     PM_TRY(pmhip_embed_rows(s2->w.tok_table, ids, tp, s2->dtype, 64, M, c.n_embed + 1, c.embed_dim, s));
-    PM_TRY(s2_tower(s2, tp, B, logits, s));
+    // softmax statistics of the logits' 64-column blocks for the sampling kernel: from the logits GEMM, or -- guided -- from the
+    // combination, which produces the logits that are sampled
+    float* lstats = nullptr;
+    if (c.n_embed % 64 == 0) WS(s2->ws, "s2.lstats", (size_t)M * (c.n_embed / 64) * 8, lstats);
+    PM_TRY(s2_tower(s2, tp, B, logits, s, true, guidance ? nullptr : lstats));
     if (guidance) {
         float* uncond;
         WS(s2->ws, "s2.logits_u", (size_t)M * c.n_embed * 4, uncond);
         PM_TRY(s2_tower(s2, tp, B, uncond, s, false));
-        PM_TRY(pmhip_guidance_combine(logits, uncond, *guidance, logits, (size_t)M * c.n_embed, s));
+        if (lstats) PM_TRY(pmhip_guidance_combine_stats(logits, uncond, *guidance, logits, (size_t)M * c.n_embed, lstats, s));
+        else PM_TRY(pmhip_guidance_combine(logits, uncond, *guidance, logits, (size_t)M * c.n_embed, s));
     }
     return PMHIP_OK;
 }
@@ -827,7 +842,9 @@ int step_tail(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, int B, int topk, floa
     WS(s2->ws, "s2.logits", (size_t)M * c.n_embed * 4, logits);
     WS(s2->ws, "s2.pred", (size_t)M * 8, pred);
     WS(s2->ws, "s2.score", (size_t)M * 4, score);
-    PM_TRY(pm_sample_rows(logits, c.n_embed, ids, (int64_t)c.n_embed, topk, temperature, noise, seed, step,
+    float* lstats = nullptr;                                 // step_tower filled them (same condition, same workspace entry)
+    if (c.n_embed % 64 == 0) WS(s2->ws, "s2.lstats", (size_t)M * (c.n_embed / 64) * 8, lstats);
+    PM_TRY(pm_sample_rows(logits, c.n_embed, lstats, ids, (int64_t)c.n_embed, topk, temperature, noise, seed, step,
                           image_base * (uint64_t)c.tokens, pred, ids, score, M, c.n_embed, gp, s));
     if (img_out) PM_TRY(decode_pred(s2, vq, B, img_out, s));
     if (pred_out) PM_HIP(hipMemcpyAsync(pred_out, pred, (size_t)M * 8, hipMemcpyDeviceToDevice, s));

@@ -343,9 +343,12 @@ int set_lnfold(GemmParams& p, const pmhip_lnfold* ln, int dtype, int epi, int ou
 
 int gemm_impl(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
                           const float* residual, int ldr, int res_rows, void* out, int ldo, int out_dtype,
-                          int M, int N, int K, const pmhip_lnfold* ln, pmhip_stream stream) {
+                          int M, int N, int K, const pmhip_lnfold* ln, pmhip_stream stream, float* block_stats = nullptr) {
     GemmParams p{};
     p.A = A; p.W = W; p.bias = bias; p.residual = residual; p.out = out;
+    p.block_stats = block_stats;
+    PM_REQUIRE(!block_stats || (out_dtype == PMHIP_F32 && !residual && N % 64 == 0),
+               "gemm_softmax_stats: block statistics need an f32 output without a residual and N=%d a multiple of 64", N);
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.res_rows = res_rows > 0 ? res_rows : M; p.ldo = ldo;
     p.M = M; p.N = N; p.K = K;
     PM_TRY(check_common(p, dtype));
@@ -426,6 +429,15 @@ extern "C" int pmhip_gemm_ln(int dtype, const void* A, int lda, const void* W, i
                              int out_dtype, int M, int N, int K, const pmhip_lnfold* ln, pmhip_stream stream) {
     PM_REQUIRE(ln, "gemm_ln: null fold descriptor");
     return gemm_impl(dtype, A, lda, W, ldw, bias, nullptr, 0, 0, out, ldo, out_dtype, M, N, K, ln, stream);
+}
+
+// out (f32) = A . W^T + bias, LayerNorm optionally folded (ln may be NULL), plus the softmax statistics of every (row, 64-column
+// block) of the result: block_stats [M][N/64][2] = (max, sum of exp), common.h softmax_block_stat.  The logits GEMM of the
+// MaskGIT step (transformer.py:91): pmhip_sample_rows_stats then reads the statistics and the top-k blocks of a row only.
+extern "C" int pmhip_gemm_softmax_stats(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, float* out, int ldo,
+                                        int M, int N, int K, const pmhip_lnfold* ln, float* block_stats, pmhip_stream stream) {
+    PM_REQUIRE(block_stats, "gemm_softmax_stats: null statistics buffer");
+    return gemm_impl(dtype, A, lda, W, ldw, bias, nullptr, 0, 0, out, ldo, PMHIP_F32, M, N, K, ln, stream, block_stats);
 }
 
 extern "C" int pmhip_lnfold_supported(int dtype, int epi_kind, int M, int N, int K) {

@@ -52,6 +52,10 @@ struct GemmParams {
     // (ln_coef_row, common.h) instead of being read; the workgroups of the first tile column also store them to ln_coef_out for
     // whoever needs them next (the centred producer that follows)
     const float* ln_parts; int ln_nparts; float ln_eps; float* ln_coef_out;
+    // f32 EPI_STD output without a residual (the logits GEMM): softmax statistics (max, sum of exp) of every (row, 64-column block),
+    // [M][N/64][2], computed from the values as they are stored (common.h, softmax_block_stat).  The sampling kernel then reads these
+    // 8 bytes per block and the top-k blocks of a row instead of the whole row (sample.hip).  N % 64 == 0.
+    float* block_stats;
 };
 
 // timing family of a launch (common.h)
@@ -586,6 +590,13 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
                         }
                     }
                     st_row<NT>(reinterpret_cast<OutT*>(p.out) + (size_t)mm * p.ldo + ncol, v);
+                    if constexpr (sizeof(OutT) == 4) {
+                        if (p.block_stats) {                       // wave-uniform; N % 64 == 0: the 16 lanes of a row are all active
+                            const float2 st = softmax_block_stat(v[0], v[1], v[2], v[3]);
+                            if ((lane & (LPR - 1)) == 0)
+                                *reinterpret_cast<float2*>(p.block_stats + ((size_t)mm * (p.N >> 6) + (nw >> 6)) * 2) = st;
+                        }
+                    }
                 }
             }
         } else if constexpr (EPI == EPI_SWIGLU) {

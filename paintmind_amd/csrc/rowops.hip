@@ -188,11 +188,20 @@ __global__ __launch_bounds__(THREADS) void add_rows_kernel(const float* __restri
 // (the reference TRAINS for this -- 10 % text drop, utils/trainer.py:379,387-388 -- but its inference never combines them; an
 // extension behind an explicit keyword).  One fused multiply-add per element in fp32, in place when out aliases cond or uncond.
 // (no __restrict__: out is documented to alias cond or uncond; every element is read and then written by the same lane)
-__global__ __launch_bounds__(THREADS) void guidance_kernel(const float* cond, const float* uncond, float scale, float* out, size_t n4) {
+// STATS: additionally the softmax statistics of every 64-element block of the result (16 consecutive lanes hold one block, four
+// consecutive elements each -- the layout of common.h softmax_block_stat): what the logits GEMM leaves behind for an unguided step.
+template <bool STATS>
+__global__ __launch_bounds__(THREADS) void guidance_kernel(const float* cond, const float* uncond, float scale, float* out, size_t n4,
+                                                           float2* block_stats) {
     for (size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * THREADS) {
         const float4 c = reinterpret_cast<const float4*>(cond)[i], u = reinterpret_cast<const float4*>(uncond)[i];
-        reinterpret_cast<float4*>(out)[i] = make_float4(fmaf(scale, c.x - u.x, u.x), fmaf(scale, c.y - u.y, u.y), fmaf(scale, c.z - u.z, u.z),
-                                                       fmaf(scale, c.w - u.w, u.w));
+        const float4 r = make_float4(fmaf(scale, c.x - u.x, u.x), fmaf(scale, c.y - u.y, u.y), fmaf(scale, c.z - u.z, u.z),
+                                     fmaf(scale, c.w - u.w, u.w));
+        reinterpret_cast<float4*>(out)[i] = r;
+        if constexpr (STATS) {                             // n4 % 16 == 0: the 16 lanes of a block run the same iterations
+            const float2 st = softmax_block_stat(r.x, r.y, r.z, r.w);
+            if ((threadIdx.x & 15) == 0) block_stats[i >> 4] = st;
+        }
     }
 }
 
@@ -511,12 +520,29 @@ extern "C" int pmhip_add_rows(const float* x, const float* table, int table_rows
     return PMHIP_OK;
 }
 
-extern "C" int pmhip_guidance_combine(const float* cond, const float* uncond, float scale, float* out, size_t n, pmhip_stream stream) {
+static int guidance_impl(const float* cond, const float* uncond, float scale, float* out, size_t n, float* block_stats, pmhip_stream stream) {
     PM_REQUIRE(cond && uncond && out, "guidance_combine: null pointer");
     PM_REQUIRE(n > 0 && n % 4 == 0, "guidance_combine: n must be a positive multiple of 4");
+    PM_REQUIRE(!block_stats || n % 64 == 0, "guidance_combine_stats: n must be a multiple of 64 (rows of whole 64-column blocks)");
     hipStream_t s = (hipStream_t)stream;
     PmTimer tm(FAM_ROWOPS, s);
-    hipLaunchKernelGGL(guidance_kernel, dim3(grid_for(n / 4)), dim3(THREADS), 0, s, cond, uncond, scale, out, n / 4);
+    if (block_stats)
+        hipLaunchKernelGGL(guidance_kernel<true>, dim3(grid_for(n / 4)), dim3(THREADS), 0, s, cond, uncond, scale, out, n / 4,
+                           reinterpret_cast<float2*>(block_stats));
+    else
+        hipLaunchKernelGGL(guidance_kernel<false>, dim3(grid_for(n / 4)), dim3(THREADS), 0, s, cond, uncond, scale, out, n / 4, (float2*)nullptr);
     PM_HIP(hipGetLastError());
     return PMHIP_OK;
+}
+
+extern "C" int pmhip_guidance_combine(const float* cond, const float* uncond, float scale, float* out, size_t n, pmhip_stream stream) {
+    return guidance_impl(cond, uncond, scale, out, n, nullptr, stream);
+}
+
+// the same, plus block_stats [n / 64][2]: softmax statistics of the combined logits for pmhip_sample_rows_stats (contiguous rows
+// whose length is a multiple of 64)
+extern "C" int pmhip_guidance_combine_stats(const float* cond, const float* uncond, float scale, float* out, size_t n, float* block_stats,
+                                            pmhip_stream stream) {
+    PM_REQUIRE(block_stats, "guidance_combine_stats: null statistics buffer");
+    return guidance_impl(cond, uncond, scale, out, n, block_stats, stream);
 }

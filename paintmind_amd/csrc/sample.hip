@@ -8,8 +8,16 @@
 // (noise is only needed at those k positions: every other position is -inf in the reference), the
 // confidence of the unfiltered softmax at the sampled id, and the merge into the masked positions.
 //
+// sample_tiles (round 5, top-k <= 8 and V a multiple of 64: every launch of the decode loop): the same step from the softmax
+// statistics of the row's 64-column blocks -- (max, sum of exp) per block, 8 bytes, left behind by the logits GEMM's epilogue
+// (gemm_common.h, GemmParams::block_stats) -- and the k blocks with the largest maxima, which contain the k largest elements:
+// 1 KiB + k x 256 B per row instead of 32 KiB.  Without statistics the kernel derives them from the stored row by the SAME
+// arithmetic (common.h softmax_block_stat), so which kernel produced them never shows in the result.
+//
 // remask: per image, the num_mask highest scores get the mask id (generate.py:175-179); bitonic sort
 // of 64-bit (score, reversed index) keys in LDS gives the exact (score desc, index asc) order.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -155,6 +163,148 @@ __global__ __launch_bounds__(THREADS) void sample_rows_kernel(
     }
 }
 
+
+// ---- the step from block statistics -----------------------------------------------------------------------------------------
+constexpr int KT_MAX = 8;                                  // top-k served by sample_tiles_kernel
+
+// NB2 = blocks per lane (block b is kept by lane b % 64).  DENSE: no statistics were handed in -- one pass over the stored row
+// computes them (lane l, group g: columns (g*64 + l)*4 .. +3, i.e. block g*4 + l/16 in the layout softmax_block_stat defines).
+template <int NB2, bool DENSE>
+__global__ __launch_bounds__(THREADS) void sample_tiles_kernel(
+    const float* __restrict__ logits, int ldl, const float2* __restrict__ stats, const int64_t* __restrict__ ids_in, int64_t mask_id,
+    int topk, float temperature, const float* __restrict__ noise, uint64_t seed, uint32_t step, uint64_t row_base,
+    int64_t* __restrict__ pred_out, int64_t* __restrict__ ids_out, float* __restrict__ score_out, int M, int V,
+    const PmGenParams* __restrict__ gp) {
+    __shared__ float2 sh[DENSE ? THREADS / 64 : 1][DENSE ? NB2 * 64 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * (THREADS / 64) + wave;
+    if (row >= M) return;                                  // whole wave exits together (no workgroup barrier below)
+    if (gp) {
+        temperature = gp->temps[step];
+        seed = gp->seed;
+        row_base = gp->row_base;
+    }
+    const float* lrow = logits + (size_t)row * ldl;
+    const int nblk = V >> 6;
+
+    float2 st[NB2];
+    if constexpr (DENSE) {
+        const int ngroups = (V + 255) >> 8;
+        for (int g0 = 0; g0 < ngroups; g0 += 8) {          // eight 1-KiB loads in flight per wave
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int col = ((g0 + u) * 64 + lane) * 4;
+                x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g0 + u < ngroups && col < V) x[u] = *reinterpret_cast<const float4*>(lrow + col);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int col = ((g0 + u) * 64 + lane) * 4;
+                const float2 b = softmax_block_stat(x[u].x, x[u].y, x[u].z, x[u].w);
+                if (g0 + u < ngroups && col < V && (lane & 15) == 0) sh[wave][(g0 + u) * 4 + (lane >> 4)] = b;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NB2; ++j) {
+            const int b = lane + 64 * j;
+            st[j] = b < nblk ? sh[wave][b] : make_float2(-INFINITY, 0.f);
+        }
+    } else {
+        const float2* srow = stats + (size_t)row * nblk;
+#pragma unroll
+        for (int j = 0; j < NB2; ++j) {
+            const int b = lane + 64 * j;
+            st[j] = b < nblk ? srow[b] : make_float2(-INFINITY, 0.f);
+        }
+    }
+    // ---- softmax normaliser of the UNfiltered row (generate.py:170) from the blocks: max M, S = sum_b s_b 2^((m_b - M) log2 e)
+    float mx = st[0].x;
+#pragma unroll
+    for (int j = 1; j < NB2; ++j) mx = fmaxf(mx, st[j].x);
+    mx = wave_max(mx);
+    const float nmx = __fmul_rn(mx, -PM_LOG2E);
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB2; ++j) se = __fmaf_rn(st[j].y, __builtin_amdgcn_exp2f(__fmaf_rn(st[j].x, PM_LOG2E, nmx)), se);
+    se = wave_sum(se);
+
+    // ---- the k blocks with the largest maxima, (max desc, block asc): they hold the k first elements of (value desc, column asc)
+    // (an element outside them has k blocks in front of its own, each with an element that comes before it)
+    int tile[KT_MAX];
+    float x[KT_MAX];
+#pragma unroll
+    for (int r = 0; r < KT_MAX; ++r) {
+        tile[r] = -1;
+        x[r] = -INFINITY;
+        if (r < topk) {                                    // wave-uniform
+            float bv = -INFINITY;
+            int bj = 0;
+#pragma unroll
+            for (int j = 0; j < NB2; ++j)
+                if (st[j].x > bv) { bv = st[j].x; bj = j; }   // strict: the lowest block wins ties
+            Cand c{bv, lane + 64 * bj};
+            c = wave_best(c);
+            if (c.v > -INFINITY) {                         // (fewer blocks than k: the remaining rounds find nothing)
+                tile[r] = __builtin_amdgcn_readfirstlane(c.i);
+#pragma unroll
+                for (int j = 0; j < NB2; ++j)
+                    if (lane + 64 * j == c.i) st[j].x = -INFINITY;
+                x[r] = lrow[tile[r] * 64 + lane];
+            }
+        }
+    }
+    // ---- top-k elements of the k x 64 values: k rounds of {per-lane best, wave arg-max, winner retires its element}
+    Cand mine{-INFINITY, 0x7fffffff};                      // candidate r is kept by lane r
+#pragma unroll
+    for (int r = 0; r < KT_MAX; ++r) {
+        if (r < topk) {
+            Cand c{-INFINITY, 0x7fffffff};
+#pragma unroll
+            for (int q = 0; q < KT_MAX; ++q) {
+                const int ci = tile[q] * 64 + lane;
+                if (tile[q] >= 0 && before(x[q], ci, c.v, c.i)) { c.v = x[q]; c.i = ci; }
+            }
+            c = wave_best(c);
+#pragma unroll
+            for (int q = 0; q < KT_MAX; ++q)
+                if (tile[q] >= 0 && tile[q] * 64 + lane == c.i) x[q] = -INFINITY;
+            if (lane == r) mine = c;
+        }
+    }
+    // ---- gumbel arg-max among the candidates (lane r evaluates candidate r)
+    Cand pert{-INFINITY, 0x7fffffff};
+    if (lane < topk && mine.i < V) {
+        float u;
+        if (noise) {
+            u = noise[(size_t)row * V + mine.i];
+        } else {
+            const uint64_t grow = row_base + (uint64_t)row;
+            const uint4 rnd = philox4x32_10(make_uint4((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)mine.i, step),
+                                            make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+            u = (float)(rnd.x >> 8) * (1.0f / 16777216.0f);
+        }
+        pert.v = mine.v / fmaxf(temperature, 1e-10f) + gumbel_from_uniform(u);
+        pert.i = mine.i;
+    }
+    const Cand win = wave_best(pert);
+    const unsigned long long owner = __ballot(lane < topk && mine.i == win.i);
+    const int src = owner ? __ffsll((long long)owner) - 1 : 0;
+    const float raw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mine.v), src));   // src is wave-uniform
+
+    if (lane == 0) {
+        const int64_t pred = win.i;
+        const int64_t cur = ids_in[row];
+        const bool is_mask = (cur == mask_id);
+        const float p = __fdiv_rn(__builtin_amdgcn_exp2f(__fmaf_rn(raw, PM_LOG2E, nmx)), se);
+        if (pred_out) pred_out[row] = pred;
+        ids_out[row] = is_mask ? pred : cur;
+        if (score_out) score_out[row] = is_mask ? (1.0f - p) : -1e5f;
+    }
+}
+
 __device__ __forceinline__ uint32_t orderable(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -195,9 +345,17 @@ __global__ __launch_bounds__(THREADS) void remask_kernel(int64_t* __restrict__ i
 
 }  // namespace
 
-int pm_sample_rows(const float* logits, int ldl, const int64_t* ids_in, int64_t mask_id, int topk, float temperature,
-                   const float* noise, uint64_t seed, uint32_t step, uint64_t row_base, int64_t* pred_out, int64_t* ids_out,
-                   float* score_out, int M, int V, const PmGenParams* gp, pmhip_stream stream) {
+static int sample_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    char* end = nullptr;
+    const long x = strtol(v, &end, 10);
+    return (end && *end == 0) ? (int)x : dflt;
+}
+
+int pm_sample_rows(const float* logits, int ldl, const float* block_stats, const int64_t* ids_in, int64_t mask_id, int topk,
+                   float temperature, const float* noise, uint64_t seed, uint32_t step, uint64_t row_base, int64_t* pred_out,
+                   int64_t* ids_out, float* score_out, int M, int V, const PmGenParams* gp, pmhip_stream stream) {
     PM_REQUIRE(logits && ids_in && ids_out, "sample_rows: null pointer");
     PM_REQUIRE(M > 0 && V > 0 && V % 4 == 0 && ldl % 4 == 0 && ldl >= V, "sample_rows: bad shape M=%d V=%d ldl=%d", M, V, ldl);
     PM_REQUIRE(topk >= 1 && topk <= 64 && topk <= V, "sample_rows: topk=%d must be in [1, min(64,V)]", topk);
@@ -205,6 +363,25 @@ int pm_sample_rows(const float* logits, int ldl, const int64_t* ids_in, int64_t 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(ceil_div(M, THREADS / 64)), block(THREADS);
     PmTimer tm(FAM_SAMPLE, s);
+    // Which kernel runs depends on (V, topk) ONLY -- never on whether statistics were handed in: the two differ in the last bits
+    // of the confidence (a different summation order of the softmax denominator).
+    static const int g_tiles = sample_env_int("PMHIP_SAMPLE_TILES", 1);     // 0: the one-read row kernel everywhere (A/B)
+    if (g_tiles && topk <= KT_MAX && V % 64 == 0) {
+        const float2* st = reinterpret_cast<const float2*>(block_stats);
+#define PM_TILES(NB2)                                                                                                         \
+    do {                                                                                                                      \
+        if (st) hipLaunchKernelGGL((sample_tiles_kernel<NB2, false>), grid, block, 0, s, logits, ldl, st, ids_in, mask_id, topk, \
+                                   temperature, noise, seed, step, row_base, pred_out, ids_out, score_out, M, V, gp);          \
+        else hipLaunchKernelGGL((sample_tiles_kernel<NB2, true>), grid, block, 0, s, logits, ldl, st, ids_in, mask_id, topk,   \
+                                temperature, noise, seed, step, row_base, pred_out, ids_out, score_out, M, V, gp);             \
+    } while (0)
+        if (V <= 4096) PM_TILES(1);
+        else if (V <= 8192) PM_TILES(2);
+        else PM_TILES(4);
+#undef PM_TILES
+        PM_HIP(hipGetLastError());
+        return PMHIP_OK;
+    }
 #define PM_SAMPLE(NV4)                                                                                              \
     hipLaunchKernelGGL((sample_rows_kernel<NV4>), grid, block, 0, s, logits, ldl, ids_in, mask_id, topk, temperature, \
                        noise, seed, step, row_base, pred_out, ids_out, score_out, M, V, gp)
@@ -221,7 +398,18 @@ extern "C" int pmhip_sample_rows(const float* logits, int ldl, const int64_t* id
                                  float temperature, const float* noise, uint64_t seed, uint32_t step,
                                  uint64_t row_base, int64_t* pred_out, int64_t* ids_out, float* score_out, int M,
                                  int V, pmhip_stream stream) {
-    return pm_sample_rows(logits, ldl, ids_in, mask_id, topk, temperature, noise, seed, step, row_base, pred_out, ids_out,
+    return pm_sample_rows(logits, ldl, nullptr, ids_in, mask_id, topk, temperature, noise, seed, step, row_base, pred_out, ids_out,
+                          score_out, M, V, nullptr, stream);
+}
+
+// the same step with the block statistics pmhip_gemm_softmax_stats (or pmhip_guidance_combine_stats) left behind: [M][V/64][2]
+extern "C" int pmhip_sample_rows_stats(const float* logits, int ldl, const float* block_stats, const int64_t* ids_in, int64_t mask_id,
+                                       int topk, float temperature, const float* noise, uint64_t seed, uint32_t step,
+                                       uint64_t row_base, int64_t* pred_out, int64_t* ids_out, float* score_out, int M, int V,
+                                       pmhip_stream stream) {
+    PM_REQUIRE(block_stats, "sample_rows_stats: null statistics");
+    PM_REQUIRE(V % 64 == 0, "sample_rows_stats: V=%d must be a multiple of 64", V);
+    return pm_sample_rows(logits, ldl, block_stats, ids_in, mask_id, topk, temperature, noise, seed, step, row_base, pred_out, ids_out,
                           score_out, M, V, nullptr, stream);
 }
 

@@ -258,6 +258,26 @@ def gemm_ln(xb, wg, coef, c, d, bias=None, out_dtype=None, parts=None):
     return out
 
 
+def gemm_softmax_stats(x, w, bias=None, fold=None):
+    """logits f32 [M,N] = x @ w.T + bias and the softmax statistics of their 64-column blocks, f32 [M, N/64, 2] = (max, sum of exp)
+    (pmhip_gemm_softmax_stats; transformer.py:91).  fold = (coef, c, d[, parts]): x is the hi plane and w the gamma-scaled weights
+    of a folded LayerNorm (gemm_ln)."""
+    dev = _dev(x, w, bias)
+    lib = _lib.load()
+    M, K = x.shape
+    N = w.shape[0]
+    if N % 64:
+        raise ValueError("gemm_softmax_stats: N must be a multiple of 64")
+    out = torch.empty(M, N, device=dev, dtype=torch.float32)
+    stats = torch.empty(M, N // 64, 2, device=dev, dtype=torch.float32)
+    ln = _lnfold(*fold) if fold is not None else None
+    with torch.cuda.device(dev):
+        check(lib.pmhip_gemm_softmax_stats(pm_dtype(x.dtype), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), N, M, N, K,
+                                           C.byref(ln) if ln is not None else None, _p(stats), stream_ptr(dev)),
+              "pmhip_gemm_softmax_stats")
+    return out, stats
+
+
 def gemm_swiglu_ln(xb, w12pg, b12p, coef, c, d, parts=None):
     dev = _dev(xb, w12pg, b12p)
     lib = _lib.load()
@@ -371,8 +391,9 @@ def add_rows(x, table):
     return out
 
 
-def guidance_combine(cond, uncond, scale, out=None):
-    """uncond + scale * (cond - uncond), fp32, same shape; `out` may be one of the inputs."""
+def guidance_combine(cond, uncond, scale, out=None, with_stats=False):
+    """uncond + scale * (cond - uncond), fp32, same shape; `out` may be one of the inputs.
+    with_stats: returns (out, block_stats [..., V/64, 2]) -- the softmax statistics sample_rows(block_stats=) takes."""
     dev = _dev(cond, uncond)
     if cond.shape != uncond.shape or cond.dtype != torch.float32 or uncond.dtype != torch.float32:
         raise ValueError("guidance_combine needs two fp32 tensors of one shape")
@@ -383,6 +404,14 @@ def guidance_combine(cond, uncond, scale, out=None):
         raise ValueError("guidance_combine needs contiguous tensors (the kernel walks them as flat arrays)")
     if cond.numel() % 4:
         raise ValueError("guidance_combine: the element count must be a multiple of 4")
+    if with_stats:
+        if cond.shape[-1] % 64:
+            raise ValueError("guidance_combine(with_stats=True): rows must be a multiple of 64 long")
+        stats = torch.empty(cond.shape[:-1] + (cond.shape[-1] // 64, 2), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            check(_lib.load().pmhip_guidance_combine_stats(_p(cond), _p(uncond), float(scale), _p(out), cond.numel(), _p(stats),
+                                                           stream_ptr(dev)), "pmhip_guidance_combine_stats")
+        return out, stats
     with torch.cuda.device(dev):
         check(_lib.load().pmhip_guidance_combine(_p(cond), _p(uncond), float(scale), _p(out), cond.numel(), stream_ptr(dev)),
               "pmhip_guidance_combine")
@@ -428,14 +457,25 @@ def vq_quantize(z, en, sq, beta=0.25):
     return z_out, idx, loss
 
 
-def sample_rows(logits, ids, mask_id, topk, temperature, noise=None, seed=0, step=0, row_base=0):
-    """logits fp32 [M,V], ids int64 [M] -> (pred [M], merged ids [M], score [M])."""
+def sample_rows(logits, ids, mask_id, topk, temperature, noise=None, seed=0, step=0, row_base=0, block_stats=None):
+    """logits fp32 [M,V], ids int64 [M] -> (pred [M], merged ids [M], score [M]).
+    block_stats fp32 [M, V/64, 2] (gemm_softmax_stats / guidance_combine(with_stats=True)): the kernel reads them and the top-k
+    blocks of a row instead of the row; same bits as without."""
     dev = _dev(logits, ids, noise)
     lib = _lib.load()
     M, V = logits.shape
     pred = torch.empty(M, device=dev, dtype=torch.int64)
     ids_out = torch.empty(M, device=dev, dtype=torch.int64)
     score = torch.empty(M, device=dev, dtype=torch.float32)
+    if block_stats is not None:
+        if (block_stats.dtype != torch.float32 or not block_stats.is_contiguous() or block_stats.device != logits.device
+                or tuple(block_stats.shape) != (M, V // 64, 2) or V % 64):
+            raise ValueError("sample_rows: block_stats must be a contiguous fp32 [M, V/64, 2] tensor on the logits' device")
+        with torch.cuda.device(dev):
+            check(lib.pmhip_sample_rows_stats(_p(logits), logits.stride(0), _p(block_stats), _p(ids), int(mask_id), int(topk),
+                                              float(temperature), _p(noise), int(seed), int(step), int(row_base), _p(pred),
+                                              _p(ids_out), _p(score), M, V, stream_ptr(dev)), "pmhip_sample_rows_stats")
+        return pred, ids_out, score
     with torch.cuda.device(dev):
         check(lib.pmhip_sample_rows(_p(logits), logits.stride(0), _p(ids), int(mask_id), int(topk), float(temperature),
                                     _p(noise), int(seed), int(step), int(row_base), _p(pred), _p(ids_out), _p(score),

@@ -601,6 +601,67 @@ def test_sample_rows_with_given_noise(V, topk, temp):
     assert np.max(np.abs(n(score) - score_r)) < 2e-6
 
 
+@pytest.mark.parametrize("V,topk", [(64, 1), (64, 5), (128, 8), (256, 3), (1024, 5), (4096, 8), (8192, 5), (8192, 8), (12288, 2), (16384, 5)])
+@pytest.mark.parametrize("ties", [False, True])
+def test_sample_rows_from_block_statistics(V, topk, ties):
+    """Round 5: for top-k <= 8 the sampling kernel works from the softmax statistics of the row's 64-column blocks (max, sum of exp)
+    and reads only the k blocks with the largest maxima.  Handed in (pmhip_sample_rows_stats) or derived from the stored row by the
+    same arithmetic (pmhip_sample_rows), the result is the same bit for bit, and it is the oracle's (ties included: quantised
+    logits put equal values in different blocks, equal block maxima, and equal values inside one block)."""
+    M = 70
+    logits = rnd(M, V, scale=3.0)
+    if ties:
+        logits = (np.round(logits * 2) / 2).astype(np.float32)
+    ids = RNG.integers(0, V, M).astype(np.int64)
+    ids[RNG.random(M) < 0.6] = V
+    noise = RNG.random((M, V)).astype(np.float32)
+    pred_r, merged_r, score_r = O.sample_rows(logits, ids, V, topk, 0.8, noise)
+    x = t(logits)
+    same, stats = ops.guidance_combine(x, x, 1.0, with_stats=True)       # u + 1 * (c - u) with c = u: the logits themselves
+    assert torch.equal(same, x) and stats.shape == (M, V // 64, 2)
+    blocks = logits.reshape(M, V // 64, 64)
+    assert np.array_equal(n(stats[..., 0]), blocks.max(-1))
+    want_sum = np.exp(blocks.astype(np.float64) - blocks.max(-1, keepdims=True)).sum(-1)
+    assert np.max(np.abs(n(stats[..., 1]) / want_sum - 1)) < 2e-6
+    dense = ops.sample_rows(x, t(ids), V, topk, 0.8, noise=t(noise))
+    sparse = ops.sample_rows(x, t(ids), V, topk, 0.8, noise=t(noise), block_stats=stats)
+    for a, b in zip(dense, sparse):
+        assert torch.equal(a, b)
+    assert np.array_equal(n(dense[0]), pred_r) and np.array_equal(n(dense[1]), merged_r)
+    assert np.max(np.abs(n(dense[2]) - score_r)) < 2e-6
+    # Philox noise: same draws either way
+    d2 = ops.sample_rows(x, t(ids), V, topk, 0.8, seed=77, step=3, row_base=1234)
+    s2 = ops.sample_rows(x, t(ids), V, topk, 0.8, seed=77, step=3, row_base=1234, block_stats=stats)
+    for a, b in zip(d2, s2):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M", [1024, 8192])                    # the 128x128 kernel / the 256x256 kernel
+@pytest.mark.parametrize("fold", [False, True])
+def test_logits_gemm_leaves_the_block_statistics_of_what_it_stores(M, fold):
+    """pmhip_gemm_softmax_stats: the logits are those of the plain call bit for bit; the statistics are the ones the sampling kernel
+    derives from the stored logits (same arithmetic, common.h softmax_block_stat) bit for bit -- checked through the kernel that
+    computes them from a stored plane (guidance_combine with cond = uncond)."""
+    D, V = 512, 8192
+    w, b = bf16_round(rnd(V, D, scale=D ** -0.5)), rnd(V)
+    if fold:
+        hi, _ = ops.split_hilo(t(rnd(M, D) + 0.4))
+        coef = ops.ln_coef(hi)
+        wg, c, d = packing.ln_fold(t(w), t(1 + 0.3 * rnd(D)), t(0.2 * rnd(D)))
+        plain = ops.gemm_ln(hi, wg, coef, c, d, bias=t(b), out_dtype=torch.float32)
+        logits, stats = ops.gemm_softmax_stats(hi, wg, bias=t(b), fold=(coef, c, d))
+    else:
+        a = t(bf16_round(rnd(M, D)), torch.bfloat16)
+        plain = ops.gemm(a, t(w, torch.bfloat16), bias=t(b), out_dtype=torch.float32)
+        logits, stats = ops.gemm_softmax_stats(a, t(w, torch.bfloat16), bias=t(b))
+    assert torch.equal(logits, plain)
+    _, want = ops.guidance_combine(logits, logits, 1.0, with_stats=True)
+    assert torch.equal(stats, want)
+    ids = torch.full((M,), V, device=dev(), dtype=torch.int64)
+    for a_, b_ in zip(ops.sample_rows(logits, ids, V, 5, 0.7, seed=5, step=1), ops.sample_rows(logits, ids, V, 5, 0.7, seed=5, step=1, block_stats=stats)):
+        assert torch.equal(a_, b_)
+
+
 def test_sample_rows_philox_matches_numpy_philox_and_is_shard_invariant():
     M, V, topk = 64, 8192, 5
     logits = rnd(M, V, scale=2.0)
