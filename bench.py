@@ -214,7 +214,11 @@ def work_per_step(workload, decode_every_step=True, kinds=None):
         gu, au = s2_step_flops(cfg, N, vq["embed_dim"], vq["n_embed"], None, kinds, B * T, B)
         gs, as_ = gs + gu, as_ + au
     gd, ad = vit_flops(vq["dec"], vq["embed_dim"], pk, False, kinds=kinds, times=B * n_dec)
-    return B * (T * gs + n_dec * gd), B * (T * as_ + n_dec * ad), B * T * N * vq["n_embed"] * 4
+    # bytes the sampling kernel reads per row: the block statistics (8 B per 64 columns) + the top-k blocks (256 B each) where the
+    # tile sampler runs (top-k <= 8, V % 64 == 0: sample.hip), else the whole fp32 row
+    V, k = vq["n_embed"], 5
+    tiles = V % 64 == 0 and k <= 8 and os.environ.get("PMHIP_SAMPLE_TILES", "1") != "0"
+    return B * (T * gs + n_dec * gd), B * (T * as_ + n_dec * ad), B * T * N * ((V // 64) * 8 + k * 256 if tiles else V * 4)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1057,7 +1061,8 @@ def main():
         if ms_g > 0:
             result["kernel_families"]["gemm"]["tflops"] = round(ach_g, 2)
         if ms_s > 0 and sample_bytes:
-            result["kernel_families"]["sample"]["logits_GBps"] = round(sample_bytes / (ms_s * 1e-3) / 1e9, 1)
+            # sampling + re-masking launches against the bytes the sampling kernel reads (block statistics + top-k blocks)
+            result["kernel_families"]["sample"]["read_GBps"] = round(sample_bytes / (ms_s * 1e-3) / 1e9, 1)
         result["end_to_end_tflops_per_gpu"] = round((gf + af) / (ms_per_step * 1e-3) / 1e12, 2)
     extra = {}
     if rank == 0 and world == 1 and pipeline and not args.final_decode_only:
