@@ -588,8 +588,13 @@ class PowerSampler:
         import re
         while not self.stop.is_set():
             try:
+                # rocm-smi is a `#!/usr/bin/env python3` script: under rocprofv3 the profiler's preloaded tool library would
+                # initialise the GPU inside `env`, whose exec of python3 the GPU boxes of this pool then refuse -- the child gets an
+                # environment without the profiler's hooks
+                env = {k: v for k, v in os.environ.items()
+                       if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS"))}
                 out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showpower", "--showclocks"], capture_output=True, text=True,
-                                     timeout=3).stdout
+                                     timeout=3, env=env).stdout
                 pw = re.search(r"Power \(W\): ([\d.]+)", out)
                 ck = re.search(r"sclk clock level: \S+ \((\d+)Mhz", out)
                 if pw and ck:
