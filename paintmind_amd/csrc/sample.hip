@@ -15,7 +15,8 @@
 // arithmetic (common.h softmax_block_stat), so which kernel produced them never shows in the result.
 //
 // remask: per image, the num_mask highest scores get the mask id (generate.py:175-179); bitonic sort
-// of 64-bit (score, reversed index) keys in LDS gives the exact (score desc, index asc) order.
+// of 64-bit (score, reversed index) keys gives the exact (score desc, index asc) order (round 5: the keys stay in registers,
+// remask_reg_kernel; the all-LDS sort is kept behind PMHIP_REMASK_REG=0).
 #include <stdlib.h>
 
 #include "common.h"
@@ -343,6 +344,75 @@ __global__ __launch_bounds__(THREADS) void remask_kernel(int64_t* __restrict__ i
     }
 }
 
+
+// Round 5: the same selection with the sort in registers.  Thread t keeps the E consecutive elements t*E .. t*E+E-1; a bitonic
+// compare-exchange with distance j is in-thread for j < E, a wave shuffle for j < 64*E and goes through LDS (two barriers) only
+// beyond that: 3 of the 55 stages at N = 1024 (the all-LDS kernel above: one barrier per stage, 40 us per launch on B <= 64
+// workgroups -- latency, not work).  Same keys, same total order, same threshold test.
+template <int E>
+__global__ __launch_bounds__(THREADS) void remask_reg_kernel(int64_t* __restrict__ ids, const float* __restrict__ scores,
+                                                             int num_mask, int64_t mask_id, int N, const PmGenParams* __restrict__ gp,
+                                                             int step) {
+    constexpr int NP = THREADS * E;
+    __shared__ unsigned long long xs[NP];
+    if (gp) num_mask = gp->nmask[step];
+    const int tid = threadIdx.x, base = tid * E;
+    const float* sc = scores + (size_t)blockIdx.x * N;
+    unsigned long long key[E], mine[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = base + e;
+        key[e] = i < N ? (((unsigned long long)orderable(sc[i]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i)) : 0ull;
+        mine[e] = key[e];
+    }
+#pragma unroll
+    for (int k = 2; k <= NP; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {                                   // both elements in this thread
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & j) == 0) {
+                        const bool desc = ((base + e) & k) == 0;
+                        const unsigned long long a = key[e], b = key[e | j];
+                        const bool swap = desc ? (a < b) : (a > b);
+                        key[e] = swap ? b : a;
+                        key[e | j] = swap ? a : b;
+                    }
+                }
+            } else {
+                unsigned long long other[E];
+                if (j < 64 * E) {                          // the partner thread is in this wave
+#pragma unroll
+                    for (int e = 0; e < E; ++e) other[e] = __shfl_xor(key[e], j / E, 64);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) xs[base + e] = key[e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < E; ++e) other[e] = xs[(base + e) ^ j];
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = base + e;
+                    const bool want_max = ((i & j) == 0) == ((i & k) == 0);   // descending block: the lower index keeps the larger key
+                    const unsigned long long a = key[e], b = other[e];
+                    key[e] = want_max ? (a > b ? a : b) : (a < b ? a : b);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) xs[base + e] = key[e];
+    __syncthreads();
+    const int nm = num_mask < 1 ? 1 : (num_mask > N ? N : num_mask);
+    const unsigned long long thr = xs[nm - 1];
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (base + e < N && mine[e] >= thr) ids[(size_t)blockIdx.x * N + base + e] = mask_id;
+}
+
 }  // namespace
 
 static int sample_env_int(const char* name, int dflt) {
@@ -421,7 +491,15 @@ int pm_remask(int64_t* ids, const float* scores, int num_mask, int64_t mask_id, 
     while (np2 < N) np2 <<= 1;
     hipStream_t s = (hipStream_t)stream;
     PmTimer tm(FAM_SAMPLE, s);
-    hipLaunchKernelGGL(remask_kernel, dim3(B), dim3(THREADS), (size_t)np2 * 8, s, ids, scores, num_mask, mask_id, N, np2, gp, step);
+    static const int g_reg = sample_env_int("PMHIP_REMASK_REG", 1);      // 0: the all-LDS sort (A/B)
+#define PM_REMASK(E) hipLaunchKernelGGL(remask_reg_kernel<E>, dim3(B), dim3(THREADS), 0, s, ids, scores, num_mask, mask_id, N, gp, step)
+    if (!g_reg) hipLaunchKernelGGL(remask_kernel, dim3(B), dim3(THREADS), (size_t)np2 * 8, s, ids, scores, num_mask, mask_id, N, np2, gp, step);
+    else if (np2 <= 256) PM_REMASK(1);
+    else if (np2 <= 512) PM_REMASK(2);
+    else if (np2 <= 1024) PM_REMASK(4);
+    else if (np2 <= 2048) PM_REMASK(8);
+    else PM_REMASK(16);
+#undef PM_REMASK
     PM_HIP(hipGetLastError());
     return PMHIP_OK;
 }

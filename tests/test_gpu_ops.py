@@ -680,7 +680,8 @@ def test_sample_rows_philox_matches_numpy_philox_and_is_shard_invariant():
     assert not np.array_equal(n(pred_c), pred_r)
 
 
-@pytest.mark.parametrize("B,N,m", [(3, 16, 8), (4, 1024, 1004), (4, 1024, 1), (2, 1024, 391), (2, 100, 37)])
+@pytest.mark.parametrize("B,N,m", [(3, 16, 8), (4, 1024, 1004), (4, 1024, 1), (2, 1024, 391), (2, 100, 37), (2, 4096, 2000), (1, 2048, 5),
+                                   (2, 513, 100), (3, 257, 256), (1, 1, 1), (2, 300, 300), (33, 1024, 722)])
 def test_remask_exact_with_ties(B, N, m):
     scores = np.round(RNG.random((B, N)).astype(np.float32), 2)        # heavy ties on purpose
     scores[:, ::7] = -1e5
