@@ -396,7 +396,10 @@ int pmhip_pipeline_sample(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const flo
  * written consecutively into imgs_out [n_decoded, B, C, H, W] (device; may be NULL when imgs_host
  * is given).  The context projection and the cross-attention K/V of the static context are
  * computed once (the reference recomputes them every step, transformer.py:84-85).
- * use_graph != 0: the loop is a chain of hipGraphs, one per segment ending in a decoded step.
+ * use_graph: bit flags.  PMHIP_GENERATE_GRAPH (1): the loop is a chain of hipGraphs, one per segment ending in a decoded step.
+ * PMHIP_GENERATE_CONCURRENT_LANES (2): the caller runs other micro-batches on other streams at the same time; the loop then never
+ * defers a step's ViT decode to a side stream (what it does on its own for B * tokens <= 16384, where one lane leaves the chip
+ * mostly idle) -- results are the same either way.
  * imgs_host != NULL replaces the reference's `imgs.append(img.cpu())` (generate.py:195-196): decoded
  * image d is copied to imgs_host + d * host_stride (floats; the caller's PINNED buffer, so that a
  * lane can fill its rows of a [n_decoded, B_total, C, H, W] tensor) on copy_stream as soon as it is
@@ -406,6 +409,8 @@ int pmhip_pipeline_sample(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const flo
  * segment always queued ahead) and returns once the last copy is enqueued; concurrent lanes are
  * driven from one thread each.  The caller synchronises copy_stream before reading the host buffer.
  * copy_stream NULL: the copies are enqueued on `stream`. */
+#define PMHIP_GENERATE_GRAPH 1
+#define PMHIP_GENERATE_CONCURRENT_LANES 2
 int pmhip_pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context,
                             int L, int B, int T, const float* temps_host, const int* nmask_host,
                             const unsigned char* decode_host, int topk, uint64_t seed,

@@ -916,7 +916,7 @@ static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const 
     // -- tools/hwtests/graph_dispatch_mode.hip, 39 of 40 replays of a chain of dependent kernels wrong with none of this library's
     // code involved -- so the loop stays eager in that mode whatever the caller asked for (same results, bit for bit)
     static const bool direct_dispatch_off = [] { const char* e = getenv("AMD_DIRECT_DISPATCH"); return e && atoi(e) == 0; }();
-    const bool graph = use_graph && !g_pm_timing_on.load() && T <= PM_MAX_STEPS && !direct_dispatch_off;
+    const bool graph = (use_graph & PMHIP_GENERATE_GRAPH) && !g_pm_timing_on.load() && T <= PM_MAX_STEPS && !direct_dispatch_off;
 
     if (imgs_host) {
         // PMHIP_BLOCKING_WAIT=1 (read when the handle is created): the lane's host thread SLEEPS in hipEventSynchronize while its
@@ -1026,7 +1026,10 @@ static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const 
     // and is joined before the first sampling kernel overwrites the predictions it reads; a last unit without steps decodes the
     // final image.  Same kernels, same inputs: bit-identical images, one unit later.
     struct Unit { int t0, t1, decode_first, delivers; bool decode_inline; };
-    const bool overlap = vq && n_dec > 0 && s2->sw.overlap_rows > 0 && (long long)B * s2->cfg.tokens <= s2->sw.overlap_rows;
+    // (not when the caller runs other lanes beside this one -- PMHIP_GENERATE_CONCURRENT_LANES: the chip is full then, and a third
+    // and fourth stream of kernels costs 5-17 % at 15-16 images per lane, profiles/r05_g_*)
+    const bool overlap = vq && n_dec > 0 && s2->sw.overlap_rows > 0 && (long long)B * s2->cfg.tokens <= s2->sw.overlap_rows &&
+                         !(use_graph & PMHIP_GENERATE_CONCURRENT_LANES);
     std::vector<Unit> units;
     {
         int d = 0, pend = -1;

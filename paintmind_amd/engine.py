@@ -314,12 +314,14 @@ class S2Engine:
         return ids, img, pred, score
 
     def generate(self, vq_engine, ids, context, temps, nmask, decode_flags, topk, seed=0, image_base=0, use_graph=False,
-                 host=None, want_device_imgs=True, guidance_scale=None):
+                 host=None, want_device_imgs=True, guidance_scale=None, concurrent_lanes=False):
         """T MaskGIT steps in one native call; returns imgs [n_decoded, B, C, H, W] (device) or None.
 
         host = (pinned float32 tensor [n_decoded, B_total, C, H, W], first row of this batch, copy stream): every decoded
         image is copied into its rows on the copy stream as soon as it is complete (the reference's `img.cpu()`,
-        generate.py:195-196); the caller synchronises that stream."""
+        generate.py:195-196); the caller synchronises that stream.
+        concurrent_lanes: other micro-batches run beside this call on other streams (PMHIP_GENERATE_CONCURRENT_LANES: the loop
+        then does not put a small batch's decode on a side stream of its own)."""
         B = ids.shape[0]
         T = len(temps)
         context, L = self._ctx(context)
@@ -341,7 +343,7 @@ class S2Engine:
         nmask_c = (C.c_int * T)(*[int(n) for n in nmask])
         dec_c = (C.c_ubyte * T)(*[1 if f else 0 for f in decode_flags])
         args = (self.handle, vq_engine.handle if vq_engine is not None else C.c_void_p(0), _p(ids), _p(context), L, B, T,
-                temps_c, nmask_c, dec_c, int(topk), int(seed), int(image_base), _p(imgs), int(use_graph),
+                temps_c, nmask_c, dec_c, int(topk), int(seed), int(image_base), _p(imgs), (1 if use_graph else 0) | (2 if concurrent_lanes else 0),
                 stream_ptr(self.device), host_ptr, host_stride, copy_stream)
         with torch.cuda.device(self.device):
             if guidance_scale is None:

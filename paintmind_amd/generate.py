@@ -364,10 +364,9 @@ class Pipeline(nn.Module):
         else:
             streams = max(1, min(int(streams), B))
             bounds = None
-            if streams == 2 and B >= 8:
-                # two lanes of EQUAL size run the same kernel sequence in lockstep and meet in the same (MFMA- or HBM-bound)
-                # kernel all the time; one image of difference lets them drift apart (measured: 445-447 -> 450-453 images/s)
-                bounds = [(0, B // 2 + 1), (B // 2 + 1, B)]
+            # equal lanes (dist.shard_range).  Rounds 3-4 gave one lane an image more (33 + 31) so that the lanes drift apart instead of
+            # meeting in the same kernel all the time: +1 % then; with the round-5 kernels the equal split is equal or better
+            # (+0.3-0.7 % at 32 + 32, +1.5 % at 16 + 16: whole 256-row tile counts per CU round, profiles/r05_g_*)
         if streams == 1:
             ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
             return eng.generate(self.vqgan.engine(), ids, context, temps, nmask, decode_flags, topk, seed=seed,
@@ -389,7 +388,7 @@ class Pipeline(nn.Module):
                 c = None if context is None else context[lo:hi].contiguous()
                 ids, imgs = e.generate(v, ids, c, temps, nmask, decode_flags, topk, seed=seed, image_base=image_base + lo,
                                        use_graph=use_graph, host=None if host is None else (host[0], lo, host[1][i]),
-                                       want_device_imgs=host is None, guidance_scale=guidance_scale)
+                                       want_device_imgs=host is None, guidance_scale=guidance_scale, concurrent_lanes=True)
             return ids, imgs, st
 
         lanes = self._lanes(streams)
