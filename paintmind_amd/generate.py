@@ -364,9 +364,13 @@ class Pipeline(nn.Module):
         else:
             streams = max(1, min(int(streams), B))
             bounds = None
-            # equal lanes (dist.shard_range).  Rounds 3-4 gave one lane an image more (33 + 31) so that the lanes drift apart instead of
-            # meeting in the same kernel all the time: +1 % then; with the round-5 kernels the equal split is equal or better
-            # (+0.3-0.7 % at 32 + 32, +1.5 % at 16 + 16: whole 256-row tile counts per CU round, profiles/r05_g_*)
+            if streams == 2 and B >= 8:
+                # two lanes of EQUAL size run the same kernel sequence in lockstep and meet in the same (MFMA- or HBM-bound)
+                # kernel all the time; one image of difference lets them drift apart (round 3: 445-447 -> 450-453 images/s).
+                # Re-measured with the round-5 kernels (profiles/r05_g_*): equal lanes are within +-1 % end to end (+0.7 % at
+                # 32 + 32, -0.8 % for paintmindv1 at 16 + 16), but every attention launch then runs beside the other lane's
+                # attention launch (132 us per launch in the bench's brackets against 123 us): the stagger stays.
+                bounds = [(0, B // 2 + 1), (B // 2 + 1, B)]
         if streams == 1:
             ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
             return eng.generate(self.vqgan.engine(), ids, context, temps, nmask, decode_flags, topk, seed=seed,
