@@ -98,6 +98,9 @@ T5_VERSION = {'t5-l': 'google/flan-t5-large', 't5-xl': 'google/flan-t5-xl', 't5-
 T5_TXT_DIM = {'t5-l': 1024, 't5-xl': 2048}      # no 't5-xxl' entry, as in the reference (generate.py:53)
 
 
+LANES_MIN_ROWS = 24 * 1024     # generate(): smallest B * tokens that runs as two concurrent micro-batch lanes by default (bf16)
+
+
 class Pipeline(nn.Module):
     def __init__(self, config, stage1_pretrained=True, stage1_checkpoint_path=None, text_model=None):
         super().__init__()
@@ -435,7 +438,8 @@ class Pipeline(nn.Module):
         """Full decode loop (generate.py:183-198): list of (B,3,H,W) CPU tensors for steps % save_interval == 0.
 
         The call is the fast path by default: the loop replays captured hipGraphs (first call eager, second call captures),
-        in bf16 mode the batch runs as two concurrent micro-batch lanes, and every saved image starts its copy into a
+        in bf16 mode a batch of at least LANES_MIN_ROWS token rows (24 images of 1024 tokens) runs as two concurrent micro-batch
+        lanes (a smaller one as one lane whose per-step decode overlaps the next step), and every saved image starts its copy into a
         pinned host buffer on a copy stream as soon as its step is done (the reference's blocking `img.cpu()` per saved
         step, generate.py:195-196), so only the last image's copy is exposed.  use_graph / streams override the defaults;
         results are bit-identical for every setting (tests/test_gpu_model.py).
@@ -465,7 +469,10 @@ class Pipeline(nn.Module):
         if use_graph is None:
             use_graph = os.environ.get("PMHIP_GENERATE_GRAPH", "1") != "0"
         if streams is None:
-            streams = 2 if (self.compute_dtype == torch.bfloat16 and B >= 8) else 1
+            # two lanes once one lane alone fills the chip: from about 24 images of 1024 tokens (tools/small_batch_lanes_ab.py,
+            # profiles/r05_g_*: at B = 8..20 ONE lane -- whose decode then overlaps the next step's tower -- is 4-15 % faster than
+            # two, at B = 24 two lanes are equal (d512) or 11 % faster (d768), +6-10 % from B = 48)
+            streams = 2 if (self.compute_dtype == torch.bfloat16 and B * self.num_tokens >= LANES_MIN_ROWS) else 1
             env_streams = os.environ.get("PMHIP_GENERATE_STREAMS")
             if env_streams:
                 try:
