@@ -398,8 +398,8 @@ int pmhip_pipeline_sample(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const flo
  * computed once (the reference recomputes them every step, transformer.py:84-85).
  * use_graph: bit flags.  PMHIP_GENERATE_GRAPH (1): the loop is a chain of hipGraphs, one per segment ending in a decoded step.
  * PMHIP_GENERATE_CONCURRENT_LANES (2): the caller runs other micro-batches on other streams at the same time; the loop then never
- * defers a step's ViT decode to a side stream (what it does on its own for B * tokens <= 32768, where one lane leaves the chip
- * mostly idle) -- results are the same either way.
+ * defers a step's ViT decode to a side stream (what it does on its own for B * tokens <= 65536: one lane alone leaves the
+ * chip partly idle: +15 % at B = 8, +1.5 % at B = 64) -- results are the same either way.
  * imgs_host != NULL replaces the reference's `imgs.append(img.cpu())` (generate.py:195-196): decoded
  * image d is copied to imgs_host + d * host_stride (floats; the caller's PINNED buffer, so that a
  * lane can fill its rows of a [n_decoded, B_total, C, H, W] tensor) on copy_stream as soon as it is

@@ -227,7 +227,7 @@ int check_dim_head(const char* who, const pmhip_tower_cfg& tc) {
 // The PMHIP_* switches are read ONCE, when a handle is created (a handle's graphs, workspace and fold decisions all depend on
 // them; a getenv on the hot path is also a data race with a caller that edits the environment from another thread).
 struct Switches {
-    int overlap_rows = 32768;   // PMHIP_DECODE_OVERLAP_MAX_ROWS: largest B * tokens whose decode loop defers each step's ViT decode
+    int overlap_rows = 65536;   // PMHIP_DECODE_OVERLAP_MAX_ROWS: largest B * tokens whose decode loop defers each step's ViT decode
                                 // to a side stream beside the next step's tower (0 = never)
     bool hilo = true;       // PMHIP_HILO=0: the fp32 stream + LayerNorm kernel of rounds 1-2
     bool fold = true;       // PMHIP_LN_UNFOLD=1: the hi/lo pair, but the separate LayerNorm kernel
