@@ -1,4 +1,4 @@
-"""Mid-size batches (B = 4..32): one lane (with the small-batch decode overlap where B * tokens <= 16384) against two lanes
+"""Mid-size batches (B = 4..64, AB_BATCHES): one lane (its decode deferred beside the next step, engine.hip) against two lanes
 (which never defer their decode since round 5) against two lanes that do (the behaviour before the fix, by monkeypatch).
 ms per 8-step generate of the headline model, hipGraph replay; alternating, best of 3 blocks of 5 calls."""
 import sys, os, time
@@ -14,8 +14,7 @@ torch.manual_seed(0)
 pipe = Pipeline(pm.Config(ver2cfg[cfg]), stage1_pretrained=False).to(dev).eval()
 pipe.set_compute_dtype(torch.bfloat16)
 ctx_dim = ver2cfg[cfg].get("context_dim")
-orig = E.S2Engine.generate if hasattr(E, "S2Engine") else None
-cls = [c for c in vars(E).values() if isinstance(c, type) and hasattr(c, "generate") and hasattr(c, "sample")][0]
+cls = E.S2Engine
 orig = cls.generate
 
 
