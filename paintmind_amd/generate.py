@@ -98,7 +98,10 @@ T5_VERSION = {'t5-l': 'google/flan-t5-large', 't5-xl': 'google/flan-t5-xl', 't5-
 T5_TXT_DIM = {'t5-l': 1024, 't5-xl': 2048}      # no 't5-xxl' entry, as in the reference (generate.py:53)
 
 
-LANES_MIN_ROWS = 24 * 1024     # generate(): smallest B * tokens that runs as two concurrent micro-batch lanes by default (bf16)
+# generate(): smallest B * tokens * width that runs as two concurrent micro-batch lanes by default (bf16).  Below it ONE lane, whose
+# per-step decode is deferred beside the next step's tower, is faster; measured crossovers (tools/small_batch_lanes_ab.py,
+# profiles/r05_g_*): d512 between 32 and 36 images, d768 between 20 and 22, d1024 between 16 and 20 -- 16-19 M in this unit.
+LANES_MIN_WORK = 17_000_000
 
 
 class Pipeline(nn.Module):
@@ -123,6 +126,7 @@ class Pipeline(nn.Module):
         self.image_size = vq_cfg['enc']['image_size']
         self.patch_size = vq_cfg['enc']['patch_size']
         self.num_tokens = (self.image_size // self.patch_size) ** 2
+        self._width = config.dim
 
         self.transformer = CondTransformer(
             vq_cfg['embed_dim'], config.dim, self.num_tokens, config.dim_head, config.mlp_dim,
@@ -438,8 +442,8 @@ class Pipeline(nn.Module):
         """Full decode loop (generate.py:183-198): list of (B,3,H,W) CPU tensors for steps % save_interval == 0.
 
         The call is the fast path by default: the loop replays captured hipGraphs (first call eager, second call captures),
-        in bf16 mode a batch of at least LANES_MIN_ROWS token rows (24 images of 1024 tokens) runs as two concurrent micro-batch
-        lanes (a smaller one as one lane whose per-step decode overlaps the next step), and every saved image starts its copy into a
+        in bf16 mode a batch of at least LANES_MIN_WORK (B * tokens * width: 33 images for d512, 22 for d768, 17 for d1024) runs
+        as two concurrent micro-batch lanes (a smaller one as one lane whose per-step decode overlaps the next step), and every saved image starts its copy into a
         pinned host buffer on a copy stream as soon as its step is done (the reference's blocking `img.cpu()` per saved
         step, generate.py:195-196), so only the last image's copy is exposed.  use_graph / streams override the defaults;
         results are bit-identical for every setting (tests/test_gpu_model.py).
@@ -469,10 +473,9 @@ class Pipeline(nn.Module):
         if use_graph is None:
             use_graph = os.environ.get("PMHIP_GENERATE_GRAPH", "1") != "0"
         if streams is None:
-            # two lanes once one lane alone fills the chip: from about 24 images of 1024 tokens (tools/small_batch_lanes_ab.py,
-            # profiles/r05_g_*: at B = 8..20 ONE lane -- whose decode then overlaps the next step's tower -- is 4-15 % faster than
-            # two, at B = 24 two lanes are equal (d512) or 11 % faster (d768), +6-10 % from B = 48)
-            streams = 2 if (self.compute_dtype == torch.bfloat16 and B * self.num_tokens >= LANES_MIN_ROWS) else 1
+            # two lanes once one lane alone fills the chip (LANES_MIN_WORK above): at B = 8..20 ONE lane -- whose decode then overlaps
+            # the next step's tower -- is 4-15 % faster than two; two lanes win from 33 (d512) / 22 (d768) / 17 (d1024) images
+            streams = 2 if (self.compute_dtype == torch.bfloat16 and B * self.num_tokens * self._width >= LANES_MIN_WORK) else 1
             env_streams = os.environ.get("PMHIP_GENERATE_STREAMS")
             if env_streams:
                 try:

@@ -11,9 +11,15 @@ from paintmind_amd import engine as E
 cfg = sys.argv[1] if len(sys.argv) > 1 else "bench-uncond-12L-d512"
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-pipe = Pipeline(pm.Config(ver2cfg[cfg]), stage1_pretrained=False).to(dev).eval()
+text_model = None
+if "text_model" not in ver2cfg[cfg]:                       # a reference preset: its T5 tower is a download, stand in for it
+    from paintmind_amd.modules.encoder import SyntheticTextEmbedder
+    from bench import context_dim_of
+    text_model = SyntheticTextEmbedder(context_dim_of(cfg))
+pipe = Pipeline(pm.Config(ver2cfg[cfg]), stage1_pretrained=False, text_model=text_model).to(dev).eval()
 pipe.set_compute_dtype(torch.bfloat16)
-ctx_dim = ver2cfg[cfg].get("context_dim")
+from bench import context_dim_of
+ctx_dim = None if cfg == "bench-uncond-12L-d512" else context_dim_of(cfg)
 cls = E.S2Engine
 orig = cls.generate
 
