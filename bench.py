@@ -41,12 +41,15 @@ if ROOT not in sys.path:
 # (tools/hwtests/graph_dispatch_mode.hip: 39 of 40 replays of a chain of dependent kernels wrong, with no code of this repository
 # involved), so the rank loop is the eager one -- bit-identical results, and at B = 64 per rank its launches hide behind the kernels.
 # PM_BENCH_RANK_GRAPH=1 keeps direct dispatch + graph replay in ranks.  A single-GPU run (the headline) is unchanged: graph replay.
-_RANK_MODE = int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("PM_BENCH_RANK_GRAPH", "0") != "1"
+# PM_BENCH_FORCE_DIST=1 (one GPU, one RCCL rank) runs exactly what a rank runs: the way to time the rank mode without a node.
+_RANK_MODE = ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PM_BENCH_FORCE_DIST") == "1")
+              and os.environ.get("PM_BENCH_RANK_GRAPH", "0") != "1")
 if _RANK_MODE:
     os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
 USE_GRAPH = os.environ.get("PM_BENCH_NO_GRAPH", "0") != "1" and os.environ.get("AMD_DIRECT_DISPATCH", "1") != "0"   # decode loop = replayed hipGraphs (captured during warm-up)
 STREAMS = int(os.environ.get("PM_BENCH_STREAMS", "2"))   # concurrent micro-batches per GPU (1 = one stream); 2 measured best
 LANE_SPLIT = os.environ.get("PM_BENCH_LANE_SPLIT")       # development: explicit micro-batch sizes, e.g. "32,16,16"
+GATHER_MODE = os.environ.get("PM_BENCH_GATHER_MODE", "lane")   # lane | side | async: how a free-running lane issues its gather (development A/B)
 PACE = int(os.environ.get("PM_BENCH_PACE", "2"))        # steps the host may run ahead of the GPU in the timed loop
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
@@ -372,13 +375,18 @@ def extra_workload(name, dtype_name, steps, device):
     model = build(name, device, dtype)
     step = make_step(name, model, device, 0)
     pipeline = WORKLOADS[name][0] is not None
+    from paintmind_amd import ops
+    ops.attention_fallbacks(reset=True, device=device)
     dt = time_steps(step, device, 2, 1, steps, pipeline and STREAMS > 1)
+    fallbacks = ops.attention_fallbacks(reset=True, device=device) if dtype_name == "bf16" else None
     ok, _ = self_check(name, model, step, device, 0)
     B, T = WORKLOADS[name][1], WORKLOADS[name][2]
     gf, af, _ = work_per_step(name)
     out = {"images_per_s": round(B / dt, 2) if ok else None, "ms_per_step": round(dt * 1e3, 3) if ok else None, "batch": B,
            "timesteps": T, "steps": steps, "dtype": dtype_name, "tflops": round((gf + af) / dt / 1e12, 1) if ok else None,
-           "self_check": "ok" if ok else "FAILED (no value is reported for a configuration that fails its check)"}
+           "self_check": "ok" if ok else "FAILED (no value is reported for a configuration that fails its check)",
+           # workgroups of the bf16 attention kernel re-run through its exact path (setup + warm-up + timed steps)
+           "attention_fallbacks": fallbacks}
     if not pipeline and dtype_name == "bf16":
         out["bf16_vs_fp32_verify"] = getattr(self_check, "last_recon_stats", None)
         out["gate"] = RECON_GATE
@@ -806,7 +814,7 @@ def main():
             if key not in recv:
                 recv[key] = [torch.empty_like(last) for _ in range(world)]
             bufs = recv[key]
-        mode = os.environ.get("PM_BENCH_GATHER_MODE", "lane")       # lane | side | async  (development A/B)
+        mode = GATHER_MODE
         if asynchronous and mode == "async":
             inflight.append((dist.gather(last, bufs, dst=0, async_op=True), last))
         elif asynchronous and mode == "side":
@@ -823,8 +831,9 @@ def main():
         return last
 
     def gather_lanes(parts):
-        """free-running lanes: every lane hands its finished images to an asynchronous gather (issued in lane order on all
-        ranks, ordered after the lane's stream); no lane and no host thread waits for RCCL inside the loop"""
+        """free-running lanes: every lane issues the gather of its finished images from its own stream (in lane order on all
+        ranks).  In the default mode that is the synchronous-API call: the LANE waits for the collective on the device (well
+        under a millisecond per step), no host thread waits for RCCL inside the loop (see gather())"""
         for lane, (_, imgs, st) in enumerate(parts):
             with torch.cuda.stream(st):
                 gather(imgs[-1], lane, asynchronous=True)
@@ -868,6 +877,9 @@ def main():
             gather(step(i))
     drain_gathers()
     log("timed region")
+    if args.dtype == "bf16":
+        from paintmind_amd import ops as _ops
+        _ops.attention_fallbacks(reset=True, device=device)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -943,8 +955,13 @@ def main():
         "config": {"workload": args.workload, "batch_per_gpu": B, "timesteps": WORKLOADS[args.workload][2],
                    "topk": 5, "decode": "final step only" if args.final_decode_only else "every step (reference-equivalent work)",
                    "parallelism": f"dp{world} (independent images, no data-path collective)",
-                   "hip_graph": bool(USE_GRAPH), "concurrent_micro_batches": STREAMS},
+                   "hip_graph": bool(USE_GRAPH), "concurrent_micro_batches": STREAMS,
+                   # what a rank of an N > 1 job runs (top of this file): the eager loop under AMD_DIRECT_DISPATCH=0
+                   "dispatch_mode": "AMD_DIRECT_DISPATCH=" + os.environ.get("AMD_DIRECT_DISPATCH", "1 (default)"),
+                   "rank_mode": bool(_RANK_MODE)},
         "images_per_s_per_gpu": round(value / world, 3),
+        # workgroups of the bf16 attention kernel that left its fixed-reference fast path in the timed steps (rank 0)
+        "attention_fallbacks": _ops.attention_fallbacks(reset=True, device=device) if args.dtype == "bf16" else None,
         "self_check": "ok", "self_check_detail": detail,
         "rccl_ranks": dist.get_world_size() if dist is not None else 0,
         "per_rank_images_per_s": [round(B * args.steps / e, 3) for e in per_rank],

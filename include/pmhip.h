@@ -397,9 +397,13 @@ int pmhip_pipeline_sample(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const flo
  * is given).  The context projection and the cross-attention K/V of the static context are
  * computed once (the reference recomputes them every step, transformer.py:84-85).
  * use_graph: bit flags.  PMHIP_GENERATE_GRAPH (1): the loop is a chain of hipGraphs, one per segment ending in a decoded step.
+ * The request is IGNORED (eager loop, same bits) while per-kernel timing is on, for T > 64, and when the process runs with
+ * AMD_DIRECT_DISPATCH=0, where graph replay is broken on ROCm 7.2 (tools/hwtests/graph_dispatch_mode.hip); bit 5 of
+ * pmhip_s2_switches tells a caller that this process is in that mode.
  * PMHIP_GENERATE_CONCURRENT_LANES (2): the caller runs other micro-batches on other streams at the same time; the loop then never
- * defers a step's ViT decode to a side stream (what it does on its own for B * tokens <= 65536: one lane alone leaves the
- * chip partly idle: +15 % at B = 8, +1.5 % at B = 64) -- results are the same either way.
+ * defers a step's ViT decode to a side stream.  The deferral exists on the GRAPH path only (fork / join inside the captured
+ * segments, for B * tokens <= 65536: one lane alone leaves the chip partly idle: +15 % at B = 8, +1.5 % at B = 64); the eager
+ * loop decodes in line -- results are the same either way.
  * imgs_host != NULL replaces the reference's `imgs.append(img.cpu())` (generate.py:195-196): decoded
  * image d is copied to imgs_host + d * host_stride (floats; the caller's PINNED buffer, so that a
  * lane can fill its rows of a [n_decoded, B_total, C, H, W] tensor) on copy_stream as soon as it is
@@ -442,7 +446,8 @@ int pmhip_pipeline_generate_guided(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, 
  * fold decisions and captured graphs depend on them); editing the environment of a live handle does nothing.  These return
  * what a handle latched: bit 0 LayerNorm fold (PMHIP_LN_UNFOLD unset), bit 1 bf16 hi/lo stream (PMHIP_HILO != 0), bit 2 row
  * statistics from the producers (PMHIP_LN_STATS != 0), bit 3 centred hi plane (PMHIP_HILO_CENTER != 0), bit 4
- * PMHIP_BLOCKING_WAIT; -1 for a NULL handle.  A tool that A/Bs a switch asserts the mode it believes it measures. */
+ * PMHIP_BLOCKING_WAIT, bit 5 (pmhip_s2_switches only; process-wide) AMD_DIRECT_DISPATCH=0: PMHIP_GENERATE_GRAPH requests run
+ * the eager loop; -1 for a NULL handle.  A tool that A/Bs a switch asserts the mode it believes it measures. */
 int pmhip_s2_switches(const pmhip_s2* h);
 int pmhip_vqgan_switches(const pmhip_vqgan* h);
 

@@ -152,21 +152,30 @@ struct Workspace {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// Stream-ordered copy of 16-byte words by a KERNEL (device memory, or pinned host memory through its device alias).  The graph-replayed
-// decode loop refreshes its per-call parameter block and ids with it: with AMD_DIRECT_DISPATCH=0 (the runtime mode whose helper
-// thread sleeps instead of busy-polling, which is what a rank of an 8-GPU job on a 16-core host wants) a hipMemcpyAsync in front of
-// a hipGraphLaunch on the same stream was observed NOT to be ordered before the graph's first kernels (tools/dispatch_mode_stress.py:
-// 12-16 of 18 replays read the previous call's seed / ids; 0 of 18 with direct dispatch, 0 of 18 eager in either mode).  A kernel
-// is a queue packet like the graph's own kernels and cannot be overtaken.
-__global__ void copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+// Stream-ordered copy by a KERNEL (device memory, or pinned host memory through its device alias): the graph-replayed decode loop
+// refreshes its per-call parameter block and ids with it, so that the refresh is a queue packet like the graph's own kernels.
+// Measured (profiles/r05_c_host_polling.txt, tools/hwtests/graph_dispatch_mode.hip): this did NOT cure the mis-ordered replays
+// seen under AMD_DIRECT_DISPATCH=0 -- graph replay itself is broken in that runtime mode on ROCm 7.2, which is why the loop runs
+// eagerly there (generate_loop) -- it is kept because it costs nothing and keeps the replay path free of hipMemcpyAsync nodes.
+// 16-byte words when size and both pointers allow it, 8-byte words otherwise (ids are int64: any B * tokens is a multiple of 8),
+// hipMemcpyAsync for anything else.
+template <typename W>
+__global__ void copy_words_kernel(W* __restrict__ dst, const W* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+template <typename W>
+int copy_words_async(void* dst, const void* src, size_t n, hipStream_t s) {
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(copy_words_kernel<W>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, (W*)dst, (const W*)src, n);
+    PM_HIP(hipGetLastError());
+    return PMHIP_OK;
 }
 int copy16_async(void* dst, const void* src, size_t bytes, hipStream_t s) {
-    PM_REQUIRE(bytes % 16 == 0 && ((uintptr_t)dst | (uintptr_t)src) % 16 == 0, "copy16: %zu bytes / pointers not 16-byte aligned", bytes);
-    const size_t n16 = bytes / 16;
-    const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 1024);
-    hipLaunchKernelGGL(copy16_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, n16);
-    PM_HIP(hipGetLastError());
+    if (bytes == 0) return PMHIP_OK;
+    const uintptr_t bits = (uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes;
+    if (bits % 16 == 0) return copy_words_async<uint4>(dst, src, bytes / 16, s);
+    if (bits % 8 == 0) return copy_words_async<unsigned long long>(dst, src, bytes / 8, s);
+    PM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s));
     return PMHIP_OK;
 }
 constexpr float kLog2e = 1.4426950408889634f;
@@ -896,6 +905,12 @@ extern "C" int pmhip_pipeline_sample_guided(pmhip_s2* s2, pmhip_vqgan* vq, int64
                        score_out, s, nullptr, &guidance_scale);
 }
 
+// process-wide: the runtime reads AMD_DIRECT_DISPATCH once when it starts, so does this
+static bool direct_dispatch_off() {
+    static const bool off = [] { const char* e = getenv("AMD_DIRECT_DISPATCH"); return e && atoi(e) == 0; }();
+    return off;
+}
+
 static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const float* context, int L, int B,
                              int T, const float* temps_host, const int* nmask_host,
                              const unsigned char* decode_host, int topk, uint64_t seed, uint64_t image_base,
@@ -915,8 +930,8 @@ static int pipeline_generate(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, const 
     // AMD_DIRECT_DISPATCH=0 (the runtime mode without the busy-polling helper thread): hipGraph replay is broken there on ROCm 7.2
     // -- tools/hwtests/graph_dispatch_mode.hip, 39 of 40 replays of a chain of dependent kernels wrong with none of this library's
     // code involved -- so the loop stays eager in that mode whatever the caller asked for (same results, bit for bit)
-    static const bool direct_dispatch_off = [] { const char* e = getenv("AMD_DIRECT_DISPATCH"); return e && atoi(e) == 0; }();
-    const bool graph = (use_graph & PMHIP_GENERATE_GRAPH) && !g_pm_timing_on.load() && T <= PM_MAX_STEPS && !direct_dispatch_off;
+    // pmhip_s2_switches reports the downgrade (bit 5) so that a caller can tell which mode ran
+    const bool graph = (use_graph & PMHIP_GENERATE_GRAPH) && !g_pm_timing_on.load() && T <= PM_MAX_STEPS && !direct_dispatch_off();
 
     if (imgs_host) {
         // PMHIP_BLOCKING_WAIT=1 (read when the handle is created): the lane's host thread SLEEPS in hipEventSynchronize while its
@@ -1144,5 +1159,7 @@ extern "C" int pmhip_pipeline_generate_guided(pmhip_s2* s2, pmhip_vqgan* vq, int
 }
 
 // the PMHIP_* switches a handle latched when it was created (bit 0 fold, 1 hilo, 2 stats, 3 center, 4 blocking_wait)
-extern "C" int pmhip_s2_switches(const pmhip_s2* h) { return h ? h->sw.key() + (h->sw.blocking_wait ? 16 : 0) : -1; }
+extern "C" int pmhip_s2_switches(const pmhip_s2* h) {
+    return h ? h->sw.key() + (h->sw.blocking_wait ? 16 : 0) + (direct_dispatch_off() ? 32 : 0) : -1;
+}
 extern "C" int pmhip_vqgan_switches(const pmhip_vqgan* h) { return h ? h->sw.key() + (h->sw.blocking_wait ? 16 : 0) : -1; }

@@ -76,7 +76,7 @@ def _pack_tower(layers, dtype, keep, stage2):
 
 def _switch_dict(bits):
     return {"ln_fold": bool(bits & 1), "hilo": bool(bits & 2), "ln_stats": bool(bits & 4), "hilo_center": bool(bits & 8),
-            "blocking_wait": bool(bits & 16)}
+            "blocking_wait": bool(bits & 16), "graph_replay_off": bool(bits & 32)}
 
 
 class VqganEngine:

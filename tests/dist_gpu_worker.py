@@ -1,9 +1,14 @@
 """One rank of the real-pipeline sharding test (started as a child process by test_gpu_dist.py).
 
-usage: dist_gpu_worker.py RANK WORLD PORT BACKEND N_PROMPTS OUT.pt
+usage: dist_gpu_worker.py RANK WORLD PORT BACKEND N_PROMPTS OUT.pt [plain]
 Builds the tiny pipeline from the committed golden weights on its GPU, runs generate_sharded() and, on rank 0,
 saves the gathered images.  With BACKEND=gloo every rank may share cuda:0 (the 1-GPU box); with nccl rank r uses
-cuda:r."""
+cuda:r.
+
+With the trailing `plain` rank 0 ALSO runs the drop-in Pipeline.generate() with its default arguments (graph replay requested)
+on the whole prompt list and saves {"sharded", "plain", "switches", "dispatch"}: the parent starts these children under
+AMD_DIRECT_DISPATCH=0 -- the runtime mode every rank of a bench.py N > 1 job is in -- and compares with its own graph-replayed
+result."""
 import os
 import sys
 
@@ -35,7 +40,11 @@ def main():
         pipe = pipe.to(dev).eval()
         prompts = [f"p{i}" for i in range(n_prompts)]
         res = generate_sharded(pipe, prompts, seed=7, timesteps=6, save_interval=2, topk=4)
-        if rank == 0:
+        if rank == 0 and len(sys.argv) > 7 and sys.argv[7] == "plain":
+            plain = pipe.generate(prompts, seed=7, timesteps=6, save_interval=2, topk=4)        # use_graph default: requested
+            torch.save({"sharded": res, "plain": plain, "switches": pipe.engine().switches,
+                        "dispatch": os.environ.get("AMD_DIRECT_DISPATCH", "unset")}, out)
+        elif rank == 0:
             torch.save(res, out)
     finally:
         dist.destroy_process_group()

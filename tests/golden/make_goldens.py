@@ -3,7 +3,7 @@ development container only -- see _ref_import.py).  The fixtures are data: seede
 reference's outputs.  Run:  python tests/golden/make_goldens.py
 
 F1  tiny_vqgan.npz / tiny_pipeline.npz / tiny_forward.npz : tiny configs, weights + inputs + intermediates
-F2  full_vqgan.npz / full_stage2.npz   : full-size configs; weights are NOT stored -- both sides
+F2  full_vqgan.npz / full_stage2.npz / full_stage2_d768.npz / full_stage2_d1024.npz : full-size configs; weights are NOT stored -- both sides
     re-create them with torch.manual_seed(seed) + create_model (bit-identical init, checked by sha256)
 F3  api.json                            : API-behaviour facts (shapes, dtypes, list lengths, errors)
 """
@@ -313,8 +313,51 @@ def full_stage2():
     return {"full_stage2_weights_sha256": sha}
 
 
+def full_stage2_text(key, out_name, img_stride):
+    """The text-conditioned BASELINE configs at full size, B = 1: cfg 4 = vit-s-vqgan + 24L/d768 with a (77, 768) context
+    (width 768 == dim: context_proj is Identity, transformer.py:58) -- the model north_star's target is quoted on -- and cfg 5 =
+    the assumed vit-b-vqgan-512 + 24L/d1024 with the same context (context_proj 768 -> 1024).  One tokens2logits + one
+    sample(topk=1) of the reference itself; weights are re-created from torch.manual_seed(0) on both sides (sha recorded)."""
+    mine = my_cfg[key]
+    ctx_dim = mine["context_dim"]
+    if mine["stage1"] not in ref_cfg:
+        ref_cfg[mine["stage1"]] = my_cfg[mine["stage1"]]
+    cfg = {k: v for k, v in mine.items() if k not in ("text_model", "context_dim")}
+    ref_cfg[key] = cfg
+    import paintmind.generate as G
+    real_ct = G.CondTransformer
+
+    def ct(*a, **k):
+        a = list(a)
+        a[8] = ctx_dim          # context_dim positional slot (generate.py:65-68): the reference sizes it from its t5 table
+        return real_ct(*a, **k)
+    G.CondTransformer = ct
+    try:
+        torch.manual_seed(0)
+        pipe = RefPipeline(ref.Config(cfg), stage1_pretrained=False).eval()
+    finally:
+        G.CondTransformer = real_ct
+    sha = sd_sha(pipe)
+    N, V = pipe.num_tokens, 8192
+    assert N == 1024
+    ctx = torch.randn(1, 77, ctx_dim, generator=torch.Generator().manual_seed(1234))
+    ids0 = torch.randint(0, V, (1, N), generator=torch.Generator().manual_seed(300))
+    ids0[0, torch.rand(N, generator=torch.Generator().manual_seed(301)) < 0.6] = V
+    logits = pipe.tokens2logits(pipe.ids2tokens(ids0), ctx)
+    ids1, img1 = pipe.sample(ids0.clone(), np.float64(0.4), text=ctx, topk=1, temperature=1.0)
+    lse = torch.logsumexp(logits, -1)
+    top2 = torch.topk(logits, 2, dim=-1).values
+    save(out_name, ids0=ids0.numpy().astype(np.int16), context=ctx.numpy(), logits_sub=logits[:, ::8, ::64].numpy(),
+         logits_argmax=logits.argmax(-1).numpy().astype(np.int16), logits_lse=lse.numpy(),
+         logits_top2gap=(top2[..., 0] - top2[..., 1]).numpy(), ids1=ids1.numpy().astype(np.int16),
+         img1_sub=img1[:, :, ::img_stride, ::img_stride].numpy(),
+         weights_sha=np.frombuffer(bytes.fromhex(sha), dtype=np.uint8))
+    return {out_name.replace(".npz", "") + "_weights_sha256": sha}
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny_vqgan", "tiny_pipeline", "tiny_forward", "full_vqgan", "full_stage2"]
+    which = sys.argv[1:] or ["tiny_vqgan", "tiny_pipeline", "tiny_forward", "full_vqgan", "full_stage2", "full_stage2_d768",
+                             "full_stage2_d1024"]
     api_path = os.path.join(HERE, "api.json")
     api = json.load(open(api_path)) if os.path.exists(api_path) else {}
     api["torch_version"] = torch.__version__
@@ -328,5 +371,9 @@ if __name__ == "__main__":
         api.update(full_vqgan())
     if "full_stage2" in which:
         api.update(full_stage2())
+    if "full_stage2_d768" in which:
+        api.update(full_stage2_text("bench-text-24L-d768", "full_stage2_d768.npz", 4))
+    if "full_stage2_d1024" in which:
+        api.update(full_stage2_text("bench-text-24L-d1024-512px", "full_stage2_d1024.npz", 8))
     json.dump(api, open(api_path, "w"), indent=2, sort_keys=True)
     print(json.dumps(api, indent=2, sort_keys=True))

@@ -68,7 +68,8 @@ def test_rank_processes_run_eagerly_without_the_polling_helper_thread():
     probe = "import os, bench; print(os.environ.get('AMD_DIRECT_DISPATCH', 'unset'), bench.USE_GRAPH)"
 
     def run(**env):
-        e = {k: v for k, v in os.environ.items() if k not in ("AMD_DIRECT_DISPATCH", "WORLD_SIZE", "PM_BENCH_RANK_GRAPH", "PM_BENCH_NO_GRAPH")}
+        e = {k: v for k, v in os.environ.items() if k not in ("AMD_DIRECT_DISPATCH", "WORLD_SIZE", "PM_BENCH_RANK_GRAPH", "PM_BENCH_NO_GRAPH",
+                                                               "PM_BENCH_FORCE_DIST")}
         e.update(env)
         return subprocess.run([sys.executable, "-c", probe], cwd=root, env=e, capture_output=True, text=True, timeout=120).stdout.split()
 
@@ -76,3 +77,4 @@ def test_rank_processes_run_eagerly_without_the_polling_helper_thread():
     assert run(WORLD_SIZE="8") == ["0", "False"]
     assert run(WORLD_SIZE="8", PM_BENCH_RANK_GRAPH="1") == ["unset", "True"]
     assert run(AMD_DIRECT_DISPATCH="0") == ["0", "False"]           # whoever sets the mode gets the eager loop
+    assert run(PM_BENCH_FORCE_DIST="1") == ["0", "False"]           # one GPU, one RCCL rank: exactly the program a rank runs

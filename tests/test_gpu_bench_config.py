@@ -104,6 +104,37 @@ def test_timed_path_graph_and_lanes_bit_identical_to_eager(name, B, L, pipe512):
         pipe.set_compute_dtype(torch.float32)
 
 
+def test_cfg5_per_gpu_share_b64_properties_and_timed_path():
+    """BASELINE configs[4] at its per-GPU share (vit-b-vqgan-512 + 24L/d1024, 77 x 768 context, B = 64), bf16, under pytest
+    (only bench.py's self_check ran this size).  Property checks as test_full_vit_s_batch64_properties: finite,
+    clamped, one residual mask token per image, and an image's result does not depend on the batch it rides in (B = 2 with the
+    same seed and image base == the first two of B = 64, Philox keyed by the global image index); then the exact timed path --
+    graph replay + two lanes -- is bit-identical to the eager single-stream loop.  T = 6 keeps it to a few seconds; the loop
+    body is the T = 18 one."""
+    name, B, T, L = "bench-text-24L-d1024-512px", 64, 6, 77
+    torch.manual_seed(0)
+    pipe = Pipeline(pm.Config(ver2cfg[name]), stage1_pretrained=False).to(dev()).eval()
+    ctx = torch.randn(B, L, ver2cfg[name]["context_dim"], generator=torch.Generator().manual_seed(1234)).to(dev())
+    flags = [False] * (T - 2) + [True, True]
+    pipe.set_compute_dtype(torch.bfloat16)
+    try:
+        from paintmind_amd import ops
+        ops.attention_fallbacks(reset=True)
+        ids, imgs = pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=77, use_graph=False, streams=1)
+        ids, imgs = ids.clone(), imgs.clone()
+        assert imgs.shape == (2, B, 3, 512, 512) and torch.isfinite(imgs).all() and float(imgs.abs().max()) <= 1.0
+        assert ((ids == pipe.mask_token_id).sum(1) == 1).all() and int(ids.max()) <= pipe.mask_token_id and int(ids.min()) >= 0
+        assert ops.attention_fallbacks() == 0
+        ids2, imgs2 = pipe.generate_ids(ctx[:2].contiguous(), 2, T, 1.0, 5, flags, seed=77, use_graph=False, streams=1)
+        assert torch.equal(ids2, ids[:2]) and torch.equal(imgs2, imgs[:, :2])
+        for rep in range(3):                                   # eager warm-up of the graph path, capture, replay
+            g_ids, g_imgs = pipe.generate_ids(ctx, B, T, 1.0, 5, flags, seed=77, use_graph=True, streams=2)
+            torch.cuda.synchronize()
+            assert torch.equal(g_ids, ids) and torch.equal(g_imgs, imgs), rep
+    finally:
+        pipe.set_compute_dtype(torch.float32)
+
+
 def test_concurrent_lanes_are_deterministic_at_dim_1024():
     """Three lanes running the stage-2 forward concurrently must reproduce their sequential results bit for bit.
     dim 1024 / 16 heads is the shape whose LayerNorm lost rows (1 % of forwards) before the wave reductions moved from

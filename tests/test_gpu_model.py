@@ -540,6 +540,45 @@ def test_full_stage2_against_reference_golden():
         assert maxabs(n(img1)[:, :, ::4, ::4], d["img1_sub"]) < TOL
 
 
+@pytest.mark.parametrize("key,name,stride", [("bench-text-24L-d768", "full_stage2_d768", 4),
+                                             ("bench-text-24L-d1024-512px", "full_stage2_d1024", 8)])
+def test_north_star_size_stage2_against_reference_golden(key, name, stride):
+    """vit-s-vqgan + 24L/d768 with a 77 x 768 context (the model north_star's target is quoted on; context_proj = Identity) and
+    cfg 5 (vit-b-vqgan-512 + 24L/d1024, context_proj 768 -> 1024) against the REFERENCE's own tokens2logits + sample(topk=1) at
+    that size (stage2/transformer.py:80-93, generate.py:159-181; tests/golden/make_goldens.py full_stage2_text), fp32-verify
+    mode: logits / lse within 1e-3, arg-max equal except at near-ties, ids explained as in the 12L/d512 test, image within
+    1e-3."""
+    from paintmind_amd.config import ver2cfg
+    _, d = load_golden(name + ".npz")
+    torch.manual_seed(0)
+    pipe = Pipeline(pm.Config(ver2cfg[key]), stage1_pretrained=False).to(dev()).eval()
+    ids0 = t(d["ids0"].astype(np.int64))
+    ctx = t(d["context"])
+    logits = pipe.tokens2logits(pipe.ids2tokens(ids0), ctx)
+    assert maxabs(n(logits)[:, ::8, ::64], d["logits_sub"]) < TOL
+    assert maxabs(n(torch.logsumexp(logits, -1)), d["logits_lse"]) < TOL
+    am = n(logits.argmax(-1))
+    bad = am != d["logits_argmax"]
+    assert np.all(d["logits_top2gap"][bad] < 1e-4), int(bad.sum())
+    eng, V, m = pipe.engine(), pipe.mask_token_id, max(int(0.4 * 1024), 1)
+    ids1, img1, pred, score = eng.sample(pipe.vqgan.engine(), ids0.clone(), ctx, 1, 1.0, m, want_img=True, want_aux=True)
+    got, want = n(ids1)[0], d["ids1"].astype(np.int64)[0]
+    pred, score, gap = n(pred)[0], n(score)[0], d["logits_top2gap"][0]
+    assert np.array_equal(pred != d["logits_argmax"][0], bad[0])
+    assert (got == V).sum() == (want == V).sum() == m
+    cutoff = np.sort(score)[-m]
+    mism = got != want
+    flip = mism & (pred != d["logits_argmax"][0])
+    edge = mism & ~flip
+    assert np.all(gap[flip] < 1e-4), gap[flip]
+    assert np.all(np.abs(score[edge] - cutoff) < 1e-5), (score[edge], cutoff)
+    assert mism.sum() <= 8, int(mism.sum())
+    img_g = pipe.vqgan.decode_from_indice(t(d["logits_argmax"].astype(np.int64)))
+    assert maxabs(n(img_g)[:, :, ::stride, ::stride], d["img1_sub"]) < TOL
+    if not bad.any():
+        assert maxabs(n(img1)[:, :, ::stride, ::stride], d["img1_sub"]) < TOL
+
+
 def test_full_size_inpaint_outpaint_against_oracle(vit_s):
     """vit-s-vqgan + 12L/d512 at B=1: Pipeline.inpaint / outpaint against O.region_loop.  Token ids from the encoder must
     equal the oracle's except at near-ties of the VQ distance (gap < 1e-5); the loop itself is compared on identical

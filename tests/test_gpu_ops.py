@@ -470,6 +470,68 @@ def test_attention_running_max_rescale_paths(dtype, pattern, Nkv):
         assert (fb == 8) if pattern == "huge_jumps" else (fb == 0), fb
 
 
+@pytest.mark.parametrize("dominance", [0.0, 10.0, 20.0, 45.0])
+def test_attention_on_trained_like_peaky_heads_reports_its_fallback_rate(dominance):
+    """What random-init models never show: heads with a logit scale of 8-12 nats (std of the scores) and a few
+    dominant keys placed AFTER key 32, i.e. outside the prefix the bf16 fast path takes its reference maximum from, scoring
+    `dominance` nats (+- 12 % by query) above a typical key.  The result must match a float64 softmax whatever path ran.  The
+    fast path holds while l = sum_j 2^(s_j - m_prefix) < 2^64 (44 nats over the prefix maximum): the test derives from the
+    float64 scores which 16-query tiles must / must not overflow, brackets the counter with that, prints the rate, and bounds
+    the cost of a launch in which workgroups fall back to 4x the fast launch."""
+    B, H, N = 2, 8, 1024
+    rng = np.random.default_rng(11)
+    sigma = np.linspace(8.0, 12.0, H, dtype=np.float32)                   # per-head logit scale, nats
+    u = rng.standard_normal(64).astype(np.float32)
+    u /= np.linalg.norm(u)
+    q = rng.standard_normal((B, H, N, 64)).astype(np.float32)
+    q += (8.0 - q @ u)[..., None] * u * 0.0 + 8.0 * u                     # a shared query component: q.u = 8 + N(0, 1)
+    k = rng.standard_normal((B, H, N, 64)).astype(np.float32)
+    k -= (k @ u)[..., None] * u                                           # ordinary keys ignore it ...
+    k *= sigma[None, :, None, None]                                       # ... and score 0.125 * q.k ~ N(0, sigma_h)
+    v = rng.standard_normal((B, H, N, 64)).astype(np.float32)
+    for pos in (40, 333, 700, 1001):                                      # ... the dominant ones gain 0.125 * (8 + n) * c = dominance * (1 + n / 8)
+        k[:, :, pos] += dominance * u
+    k, v = bf16_round(k), bf16_round(v)
+    qs = bf16_round(q * (0.125 * ops.LOG2E))
+    s2 = qs.astype(np.float64) @ k.astype(np.float64).transpose(0, 1, 3, 2)          # scores in octaves, as the kernel sees them
+    log2_l = np.log2(np.exp2(s2 - s2[..., :32].max(-1, keepdims=True)).sum(-1))       # per query; the kernel tests l < 2^64
+    s = s2 * np.log(2.0)
+    s -= s.max(-1, keepdims=True)
+    pr = np.exp(s)
+    pr /= pr.sum(-1, keepdims=True)
+    ref = (pr @ v.astype(np.float64)).transpose(0, 2, 1, 3).reshape(B * N, H * 64)
+    bf = torch.bfloat16
+    tq, tk, tvt = t(qs, bf), t(k, bf), t(np.ascontiguousarray(v.transpose(0, 1, 3, 2)), bf)
+    ops.attention_fallbacks(reset=True)
+    out = n(ops.attention(tq, tk, tvt, N, use_exp2=True))
+    fb = ops.attention_fallbacks(reset=True)
+    must = (log2_l > 64.5).reshape(B, H, N // 256, 256).any(-1).sum()             # a workgroup holds at most 256 queries ...
+    may = (log2_l > 63.5).reshape(B, H, N // 16, 16).any(-1).sum()                # ... and decides per 16-query tile
+
+    def timed(a, b, c):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ops.attention(a, b, c, N, use_exp2=True)
+        e0.record()
+        for _ in range(10):
+            ops.attention(a, b, c, N, use_exp2=True)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 10
+
+    ms = timed(tq, tk, tvt)
+    g = torch.Generator().manual_seed(1)
+    plain = [(torch.randn(B, H, N, 64, generator=g) * 0.18).to(dev()).to(bf), torch.randn(B, H, N, 64, generator=g).to(dev()).to(bf),
+             torch.randn(B, H, 64, N, generator=g).to(dev()).to(bf)]
+    ms_plain = timed(*plain)
+    ops.attention_fallbacks(reset=True)
+    print(f"dominance {dominance} nats, head logit scale 8-12 nats: max l over the 32-key prefix reference 2^{float(log2_l.max()):.1f} "
+          f"(limit 2^64), workgroups re-run {fb} (must {int(must)}, may {int(may)}), {ms * 1e3:.1f} us per launch vs {ms_plain * 1e3:.1f} us "
+          f"on random data")
+    assert np.isfinite(out).all() and rel_err(out, ref) < 4e-2, rel_err(out, ref)
+    assert (fb >= 1 if must else True) and fb <= may, (fb, int(must), int(may))
+    assert ms < 4.0 * ms_plain + 0.05, (ms, ms_plain)
+
+
 def test_attention_fallback_is_per_workgroup_and_matches_the_exact_result():
     """One (batch, head) of eight carries a key that overflows the fast path: exactly its query blocks are redone, the other
     heads are untouched bit for bit, and the redone head equals what the exact path gives on its own (Nkv = 100 is ragged and

@@ -161,6 +161,37 @@ def test_torch_port_matches_goldens(tv, tp):
         assert np.array_equal(ids.numpy(), d2["s5_ctx_ids"]) and maxabs(img.numpy(), d2["s5_ctx_img"]) < 5e-5
 
 
+@pytest.mark.parametrize("key,name", [("bench-text-24L-d768", "full_stage2_d768"), ("bench-text-24L-d1024-512px", "full_stage2_d1024")])
+def test_north_star_size_models_weights_and_oracle_against_the_reference(key, name):
+    """The model north_star's target is quoted on (24L/d768, 77 x 768 context, context_proj = Identity) and cfg 5's stage 2
+    (24L/d1024, context_proj 768 -> 1024), against the REFERENCE's own output at that size (make_goldens.py full_stage2_text):
+    the seeded init reproduces the reference's weights bit for bit (sha256), and the torch port of the oracle -- what the GPU
+    tests of these configs compare with at larger batches -- reproduces its logits."""
+    import hashlib
+    import torch
+    import paintmind_amd as pm
+    from paintmind_amd.generate import Pipeline
+    from oracle import torch_port as TP
+    from util import api_facts
+    _, d = load_golden(name + ".npz")
+    torch.manual_seed(0)
+    pipe = Pipeline(pm.Config(pm.ver2cfg[key]), stage1_pretrained=False).eval()
+    h = hashlib.sha256()
+    sd = {k: v for k, v in pipe.state_dict().items() if not k.startswith("text_model")}
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.numpy().tobytes())
+    assert h.hexdigest() == api_facts()[name + "_weights_sha256"] == bytes(d["weights_sha"]).hex()
+    ids0 = torch.from_numpy(d["ids0"].astype(np.int64))
+    table = torch.cat([sd["vqgan.quantize.embedding.weight"], sd["mask_token"]])
+    with torch.no_grad():
+        logits = TP.cond_transformer(table[ids0], torch.from_numpy(d["context"]), sd, s2_cfg(key))
+    assert maxabs(logits[:, ::8, ::64].numpy(), d["logits_sub"]) < 1e-4
+    assert maxabs(torch.logsumexp(logits, -1).numpy(), d["logits_lse"]) < 1e-4
+    bad = logits.argmax(-1).numpy() != d["logits_argmax"]
+    assert np.all(d["logits_top2gap"][bad] < 1e-4)
+
+
 # ---- masked-token objective, forward only (generate.py:78-146) ---------------------------------------
 @pytest.fixture(scope="module")
 def tf():
