@@ -110,32 +110,20 @@ __device__ __forceinline__ f32x4_t mma(const v4u_t& rows, const v4u_t& cols, con
 // wave and per CU -- needs 13 % MORE cycles, 2.45e6 against 2.16e6 per launch, MFMA busy 0.49 against 0.55: the 8-wave barrier
 // per tile costs more than the DMA saves; two independent 4-wave workgroups cover each other's barrier waits.  The patch is
 // tools/ab_variants/attn_wv8.patch, the numbers profiles/r05_a_attention_gen4_ab.txt (5).)
-template <bool EXP2, int QF>
-__global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
-                                                                    const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
-                                                                    int ldo, int heads, int Nq, int Nkv, int Nkv_pad, int nqb) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[RING * STAGE_BYTES];   // K / V^T ring
-
+// The work of ONE workgroup (4 waves x 16 QF queries of one (batch, head), first query `qbase`) as a device function: it is the
+// body of attention_bf16_kernel below, and -- ONLY_EXACT, every half-tile through the exact path -- the re-run of a workgroup of
+// the one-wave-per-SIMD kernel (attention_bf16_w1_kernel) whose fast path overflowed.  start_mask: the 16-query tiles of this
+// wave that the exact attempt stores (ONLY_EXACT), all of them otherwise.
+template <bool EXP2, int QF, bool ONLY_EXACT>
+__device__ __forceinline__ void attention_wg(unsigned char* lds, int* redo_vote, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
+                                             const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out, int ldo, int heads, int Nq, int Nkv,
+                                             int Nkv_pad, int bh, int qbase, unsigned start_mask) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    // 1-D grid.  Workgroup L runs on XCD L % 8 (private 4 MiB L2): give all query blocks of one (batch, head) the
-    // same L % 8 so its K / V^T (256 KiB) are fetched from HBM once and re-read from that XCD's L2.
-    int bh, qblk;
-    {
-        const int L = blockIdx.x, total_bh = gridDim.x / nqb;
-        if ((total_bh & 7) == 0) {
-            const int slot = L >> 3;
-            qblk = slot % nqb;
-            bh = (slot / nqb) * 8 + (L & 7);
-        } else {
-            qblk = L % nqb;
-            bh = L / nqb;
-        }
-    }
     const int b = bh / heads, h = bh % heads;
-    const int q0 = qblk * (4 * QF * 16) + wave * (QF * 16);
+    const int q0 = qbase + wave * (QF * 16);
 
     const bf16_t* Qbh = Q + (size_t)bh * Nq * DH;
     const unsigned char* Kbh = reinterpret_cast<const unsigned char*>(Kp + (size_t)bh * Nkv_pad * DH);
@@ -164,7 +152,7 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
     const unsigned vfrag_lane0 = lds_base + 8192u + (unsigned)l15 * 128u + (unsigned)(((0 + g) ^ (l15 & 7)) << 4);
     const unsigned vfrag_lane1 = lds_base + 8192u + (unsigned)l15 * 128u + (unsigned)(((4 + g) ^ (l15 & 7)) << 4);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int q0u = qblk * (4 * QF * 16) + wave_u * (QF * 16);       // q0, provably wave-uniform
+    const int q0u = qbase + wave_u * (QF * 16);                      // q0, provably wave-uniform (qbase derives from blockIdx)
 
     // one K tile + one V^T tile by DMA, 1 KiB per wave-instruction; the bank swizzle (slot ^ row) is applied to the SOURCE
     // address (kvoff / vvoff) and again on the read side
@@ -411,8 +399,6 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
 
     constexpr std::true_type Y{};
     constexpr std::false_type N{};
-    __shared__ int redo_vote[4];
-
     const int nh_full = 2 * (Nkv / KT);                      // half-tiles that lie in full tiles
     // A context without a ragged tile (self-attention: every stage-2 / ViT launch of the decode loop) runs ALL its half-tiles,
     // the last two included, through the fast step.  Past the end `step` still computes S^T(h+1) and prefetches K(h+2) / V^T(h+1):
@@ -420,8 +406,8 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
     // produce is consumed.
     const bool all_steady = (Nkv % KT) == 0 && ntiles >= 3;
     const int steady_end = all_steady ? nhalves - 1 : min(nhalves - 3, nh_full - 2);   // one bound: the loop's shape is unchanged
-    bool exact = steady_end <= 0;                            // workgroup-uniform: no fast step at all, or second attempt
-    unsigned redo_mask = ~0u;                                // tiles the exact attempt stores (all, unless it is a second attempt)
+    bool exact = ONLY_EXACT || steady_end <= 0;              // workgroup-uniform: no fast step at all, or second attempt
+    unsigned redo_mask = start_mask;                              // tiles the exact attempt stores (all, unless it is a second attempt)
 
     // O = O^T / l, head-major inside the output row, for the 16-query tiles in `mask`.  The wave's output rows go through the
     // (idle) K / V^T ring, so that every global store instruction writes 8 whole 128-byte rows (non-temporal)
@@ -514,6 +500,379 @@ __global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t
     finalize(redo_mask);                                     // the common case: every tile, straight from the fast path
 }
 
+template <bool EXP2, int QF>
+__global__ __launch_bounds__(THREADS, 2) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
+                                                                    const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
+                                                                    int ldo, int heads, int Nq, int Nkv, int Nkv_pad, int nqb) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RING * STAGE_BYTES];   // K / V^T ring
+    __shared__ int redo_vote[4];
+    // 1-D grid.  Workgroup L runs on XCD L % 8 (private 4 MiB L2): give all query blocks of one (batch, head) the
+    // same L % 8 so its K / V^T (256 KiB) are fetched from HBM once and re-read from that XCD's L2.
+    int bh, qblk;
+    {
+        const int L = blockIdx.x, total_bh = gridDim.x / nqb;
+        if ((total_bh & 7) == 0) {
+            const int slot = L >> 3;
+            qblk = slot % nqb;
+            bh = (slot / nqb) * 8 + (L & 7);
+        } else {
+            qblk = L % nqb;
+            bh = L / nqb;
+        }
+    }
+    attention_wg<EXP2, QF, false>(lds, redo_vote, Q, Kp, Vt, out, ldo, heads, Nq, Nkv, Nkv_pad, bh, qblk * (4 * QF * 16), ~0u);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Fifth generation (round 6): ONE wave per SIMD, 128 queries per wave, and a register file the kernel owns.
+//
+// Why.  Round 5's ablations put 22 % of the fourth-generation kernel in operand movement: every wave reads the whole K / V^T tile
+// from LDS (one fragment feeds 4 MFMAs) and issues a quarter of the tile's DMA.  128 queries per wave halve both per flop; that is
+// ONE wave per SIMD with the whole 512-register file.  hipcc does not place that layout by itself (given the MFMA builtins it used
+// the accumulator half as spill space: 208 v_accvgpr_read + 88 v_accvgpr_write per tile), so here the placement is stated:
+//   AGPRs (224): O^T 8 x 4 accumulator quads, l 8 quads, the Q fragments 8 x 2 x 4 -- only ever touched by MFMAs in the loop
+//                (accumulate in place / B operand), through inline-asm MFMAs with "a" constraints;
+//   VGPRs (~200): S^T of one half-tile (64), -m (32), P (32), the K and V^T fragments double-buffered (64), addresses.
+// Every instruction of the steady loop is an asm volatile statement, so the stream is exactly the source order (hipcc only
+// allocates registers); the hazards hipcc would pad are kept apart by construction: an S^T quad is read by v_exp a whole group (9
+// MFMAs) after the MFMA that wrote it, P is packed a group before the MFMA that reads it, a pack follows its exponentials by >= 2
+// instructions, and the accumulators are read by VALU only behind the s_nops after the loop.
+//
+// Arithmetic: per 16-query tile exactly the fourth generation's -- same MFMA chains in the same half-tile order, same fixed
+// reference maximum, same exp2 / pack / row-sum-by-MFMA -- so the bits of a tile do not depend on which kernel computed it (batch
+// invariance), and the post-hoc overflow vote is the same; a workgroup that fails it stores its good tiles and re-runs as two
+// fourth-generation exact workgroups (attention_wg<.., ONLY_EXACT>).
+// Taken by pm_attention_bf16 for exp2 launches with whole 64-key tiles, >= 3 of them, Nq % 512 == 0 and enough workgroups.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define W1_MFMA_QK0(d, kfr, qa, c) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(kfr), "a"(qa), "v"(c))
+#define W1_MFMA_QK1(d, kfr, qa) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(kfr), "a"(qa))
+#define W1_MFMA_ACC(d, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b))
+#if ABL & 1
+#define W1_EXP(d, s) asm volatile("v_mul_f32 %0, 1.0, %1" : "=v"(d) : "v"(s))
+#else
+#define W1_EXP(d, s) asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(s))
+#endif
+#define W1_PK(d, lo, hi) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi))
+
+constexpr int W1_QF = 8;                                     // 16-query tiles per wave
+constexpr int W1_QUERIES = 4 * W1_QF * 16;                   // per workgroup
+
+__global__ __launch_bounds__(THREADS, 1) void attention_bf16_w1_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
+                                                                       const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
+                                                                       int ldo, int heads, int Nq, int Nkv, int Nkv_pad, int nqb) {
+    constexpr int QF = W1_QF;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RING * STAGE_BYTES];   // K / V^T ring; the epilogue's staging
+    __shared__ int redo_vote[4];
+    int bh, qblk;
+    {
+        const int L = blockIdx.x, total_bh = gridDim.x / nqb;
+        if ((total_bh & 7) == 0) {
+            const int slot = L >> 3;
+            qblk = slot % nqb;
+            bh = (slot / nqb) * 8 + (L & 7);
+        } else {
+            qblk = L % nqb;
+            bh = L / nqb;
+        }
+    }
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int b = bh / heads, h = bh % heads;
+    const int qbase = qblk * W1_QUERIES;
+    const int q0 = qbase + wave * (QF * 16);
+
+    const bf16_t* Qbh = Q + (size_t)bh * Nq * DH;
+    const unsigned char* Kbh = reinterpret_cast<const unsigned char*>(Kp + (size_t)bh * Nkv_pad * DH);
+    const unsigned char* Vbh = reinterpret_cast<const unsigned char*>(Vt + (size_t)bh * DH * Nkv_pad);
+    const unsigned v_row_bytes = (unsigned)Nkv_pad * 2u;
+    // DMA descriptors, lane offsets and fragment addresses: the fourth generation's (see attention_wg)
+    const rsrc_t Kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Kbh), 0, 0x7fffffff, 0x00020000);
+    const rsrc_t Vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Vbh), 0, 0x7fffffff, 0x00020000);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned lslot = (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+    const unsigned kvoff = (unsigned)(lane >> 3) * 128u + lslot;
+    const unsigned kvoff1 = PM_ATTN_KSWZ ? kvoff ^ 64u : kvoff;
+    const unsigned vvoff = (unsigned)(lane >> 3) * v_row_bytes + lslot;
+    const unsigned kfrag_lane = lds_base + (unsigned)(8 * (l15 >> 2) + (l15 & 3)) * 128u + (unsigned)((g4 ^ (l15 & 3)) << 4) +
+                                (PM_ATTN_KSWZ ? (unsigned)(((l15 >> 2) & 1) << 6) : 0u);
+    const unsigned kfrag_laneB = kfrag_lane ^ 64u;
+    const unsigned vfrag_lane0 = lds_base + 8192u + (unsigned)l15 * 128u + (unsigned)(((0 + g4) ^ (l15 & 7)) << 4);
+    const unsigned vfrag_lane1 = lds_base + 8192u + (unsigned)l15 * 128u + (unsigned)(((4 + g4) ^ (l15 & 7)) << 4);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int q0u = qbase + wave_u * (QF * 16);
+
+    auto stage_tiles = [&](int t) {
+        unsigned char* stage = lds + (t % RING) * STAGE_BYTES;
+        const unsigned kv0 = (unsigned)t * KT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned chunk = (unsigned)wave_u * 2 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Kr, (__attribute__((address_space(3))) void*)(stage + chunk * 1024), 16, i ? kvoff1 : kvoff,
+                                                     (kv0 + chunk * 8) * 128u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Vr, (__attribute__((address_space(3))) void*)(stage + KT * 128 + chunk * 1024), 16, vvoff,
+                                                     chunk * 8 * v_row_bytes + kv0 * 2u, 0, 0);
+        }
+    };
+
+    const int ntiles = Nkv / KT;
+    const int nhalves = 2 * ntiles;
+
+    // ---- registers the kernel owns
+    v4u_t qa[QF][2];                     // AGPR: Q fragments (column operand of S^T)
+    f32x4_t o[4][QF];                    // AGPR: O^T accumulators
+    f32x4_t lacc[QF];                    // AGPR: row sums (every element = l of the query column)
+    f32x4_t negm[QF];                    // -m_ref x4: the C operand of the S^T MFMAs
+    f32x4_t s0[QF], s1[QF];              // S^T of ONE half-tile: key sub-tiles kk = 0 / 1
+    unsigned pf[QF][4];                  // P^T operand of the 16-query tiles (bf16 pairs)
+    v4u_t kfE[2][2], kfO[2][2], vfE[4], vfO[4];       // K / V^T fragments of the even / odd half-tiles
+    v4u_t ones = v4u_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    asm volatile("" : "+v"(ones));
+
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        const unsigned char* qrow = reinterpret_cast<const unsigned char*>(Qbh + (size_t)(q0 + qf * 16 + l15) * DH);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            qa[qf][c] = *reinterpret_cast<const v4u_t*>(qrow + (c * 4 + g4) * 16);
+            asm volatile("" : "+a"(qa[qf][c]));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < QF; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+a"(o[i][j])); }
+        lacc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+a"(lacc[j]));
+        negm[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+v"(negm[j]));        // materialised HERE: hipcc otherwise writes the zero quad in the instruction before the
+    }                                            // first asm MFMA that reads it as C (VALU write -> MFMA operand needs wait states it
+                                                 // cannot know about: the first MFMA's tile came out wrong in ~90 % of the workgroups)
+
+    // fragment reads of half-tile hh
+#define W1_KADDR(hh) ((unsigned)(((hh) >> 1) % RING) * STAGE_BYTES + (unsigned)((hh) & 1) * 4096u)
+#define W1_VADDR(hh) ((((hh) & 1) ? vfrag_lane1 : vfrag_lane0) + (unsigned)(((hh) >> 1) % RING) * STAGE_BYTES)
+
+    // entering tile tn: its DMA has landed (counted wait: the younger tile's pieces may still fly), the barrier publishes it and proves
+    // that every wave is done with tile tn - 2, whose ring stage the DMA of tile tn + AHEAD reuses
+    auto enter_tile = [&](int tn) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 8) || tn == 0) {
+            if (tn + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (tn + AHEAD < ntiles && !(ABL & 4)) stage_tiles(tn + AHEAD);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- first half-tile: S^T(0) from C = 0, the reference maximum of every query, S^T(0) - m_ref (exactly attention_wg's
+    //      qk + rescale(first) for a context without ragged tiles)
+    stage_tiles(0);
+    stage_tiles(1);
+    enter_tile(0);
+    {
+        const unsigned so = W1_KADDR(0), ka = kfrag_lane + so, kb = kfrag_laneB + so;
+        DSRX(kfE[0][0], ka, 0 * 512); DSRX(kfE[0][1], kb, 0 * 512); DSRX(kfE[1][0], kb, 1 * 512); DSRX(kfE[1][1], ka, 1 * 512);
+        LGKM4(0, kfE[0][0], kfE[0][1], kfE[1][0], kfE[1][1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 3" ::: "memory");        // whatever hipcc wrote last (an operand of the first MFMA?) has been written
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) W1_MFMA_QK0(s0[qf], kfE[0][0], qa[qf][0], negm[qf]);
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) W1_MFMA_QK1(s0[qf], kfE[0][1], qa[qf][1]);
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) W1_MFMA_QK0(s1[qf], kfE[1][0], qa[qf][0], negm[qf]);
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) W1_MFMA_QK1(s1[qf], kfE[1][1], qa[qf][1]);
+    // MFMA result -> VALU: hipcc does not see the asm MFMAs and pads nothing; nothing may be scheduled across the wait states
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        float m = vmax3(s0[qf][0], s0[qf][1], s0[qf][2]);
+        m = vmax3(m, s0[qf][3], s1[qf][0]);
+        m = vmax3(m, s1[qf][1], s1[qf][2]);
+        m = vmax2(m, s1[qf][3]);
+        const float mnew = vmax3(-INFINITY, group4_max(m) + 0.f, -1e30f);
+        const float delta = 0.f - mnew;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[qf][r] += delta; s1[qf][r] += delta; }
+        negm[qf][0] = delta; negm[qf][1] = delta; negm[qf][2] = delta; negm[qf][3] = delta;
+    }
+    {   // K(1), V^T(0); P(0, 0)
+        const unsigned so = W1_KADDR(1), ka = kfrag_lane + so, kb = kfrag_laneB + so, va = W1_VADDR(0);
+        DSRX(kfO[0][0], ka, 0 * 512); DSRX(kfO[0][1], kb, 0 * 512); DSRX(kfO[1][0], kb, 1 * 512); DSRX(kfO[1][1], ka, 1 * 512);
+        DSRX(vfE[0], va, 0 * 2048); DSRX(vfE[1], va, 1 * 2048); DSRX(vfE[2], va, 2 * 2048); DSRX(vfE[3], va, 3 * 2048);
+        float e[8];
+        W1_EXP(e[0], s0[0][0]); W1_EXP(e[1], s0[0][1]); W1_EXP(e[2], s0[0][2]); W1_EXP(e[3], s0[0][3]);
+        W1_EXP(e[4], s1[0][0]); W1_EXP(e[5], s1[0][1]); W1_EXP(e[6], s1[0][2]); W1_EXP(e[7], s1[0][3]);
+        W1_PK(pf[0][0], e[0], e[1]); W1_PK(pf[0][1], e[2], e[3]); W1_PK(pf[0][2], e[4], e[5]); W1_PK(pf[0][3], e[6], e[7]);
+    }
+
+    // ---- one half-tile step.  On entry: s0 / s1 = S^T(hh) - m_ref with tile 0 already turned into pf[0]; K(hh+1) and V^T(hh) in
+    //      the fragment registers of their parity (requested during the previous step).  Group g:
+    //        matrix:  S^T(hh+1, g) = K(hh+1) Q_g - m_ref (4), O^T(., g) += V^T(hh) P(hh, g) (4), l_g += 1 P(hh, g) (1)
+    //        vector:  P(hh, g+1) = bf16(exp2(S^T(hh, g+1)))   (g = 7: P(hh+1, 0) from this step's group 0)
+    //      interleaved  M T T M T T M P M T T M P M T T M P M P M: a pack never directly follows its exponentials (the consumer of a
+    //      transcendental needs a wait state, and an in-order wave would stall the next MFMA's issue behind it).  The V^T(hh+1) / K(hh+2) fragments are requested one pair per group into the registers of the
+    //      other parity; an even step enters the next tile (wait + barrier + DMA of the tile after next) before it reads K(hh+2).
+    //      QK = false (last step): no S^T(hh+1), no exponentials.  NEXTK = false: no K(hh+2).  NEXTV = false: no V^T(hh+1).
+#define W1_GROUP(g, kN, vC, DOQK)                                                                                        \
+    {                                                                                                                    \
+        constexpr int nx = ((g) + 1) % QF;                                                                               \
+        constexpr bool DOEXP = (DOQK) || (g) + 1 < QF;      /* last step: P(hh, g+1) still, but no P(hh+1, 0) */          \
+        float e[8];                                                                                                      \
+        const v4u_t pv = v4u_t{pf[g][0], pf[g][1], pf[g][2], pf[g][3]};                                                  \
+        if (DOQK) W1_MFMA_QK0(s0[g], kN[0][0], qa[g][0], negm[g]);                                                       \
+        if (DOEXP) { W1_EXP(e[0], s0[nx][0]); W1_EXP(e[1], s0[nx][1]); }                                                 \
+        if (DOQK) W1_MFMA_QK0(s1[g], kN[1][0], qa[g][0], negm[g]);                                                       \
+        if (DOEXP) { W1_EXP(e[2], s0[nx][2]); W1_EXP(e[3], s0[nx][3]); }                                                 \
+        if (DOQK) W1_MFMA_QK1(s0[g], kN[0][1], qa[g][1]);                                                                \
+        if (DOEXP) W1_PK(pf[nx][0], e[0], e[1]);                                                                         \
+        if (DOQK) W1_MFMA_QK1(s1[g], kN[1][1], qa[g][1]);                                                                \
+        if (DOEXP) { W1_EXP(e[4], s1[nx][0]); W1_EXP(e[5], s1[nx][1]); }                                                 \
+        W1_MFMA_ACC(o[0][g], vC[0], pv);                                                                                 \
+        if (DOEXP) W1_PK(pf[nx][1], e[2], e[3]);                                                                         \
+        W1_MFMA_ACC(o[1][g], vC[1], pv);                                                                                 \
+        if (DOEXP) { W1_EXP(e[6], s1[nx][2]); W1_EXP(e[7], s1[nx][3]); }                                                 \
+        W1_MFMA_ACC(o[2][g], vC[2], pv);                                                                                 \
+        if (DOEXP) W1_PK(pf[nx][2], e[4], e[5]);                                                                         \
+        W1_MFMA_ACC(o[3][g], vC[3], pv);                                                                                 \
+        if (DOEXP) W1_PK(pf[nx][3], e[6], e[7]);                                                                         \
+        W1_MFMA_ACC(lacc[g], ones, pv);                                                                                  \
+    }
+#define W1_RDK(kD, hh2)                                                                                                  \
+    { const unsigned so_ = W1_KADDR(hh2), ka_ = kfrag_lane + so_, kb_ = kfrag_laneB + so_;                               \
+      DSRX(kD[0][0], ka_, 0 * 512); DSRX(kD[0][1], kb_, 0 * 512); DSRX(kD[1][0], kb_, 1 * 512); DSRX(kD[1][1], ka_, 1 * 512); }
+#define W1_RDV(vD, hh1)                                                                                                  \
+    { const unsigned va_ = W1_VADDR(hh1);                                                                                \
+      DSRX(vD[0], va_, 0 * 2048); DSRX(vD[1], va_, 1 * 2048); DSRX(vD[2], va_, 2 * 2048); DSRX(vD[3], va_, 3 * 2048); }
+    // all fragment reads of the previous step have landed (they were issued >= 4 groups ago: the wait is free)
+#define W1_LANDED(kN, vC) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kN[0][0]), "+v"(kN[0][1]), "+v"(kN[1][0]), "+v"(kN[1][1]), \
+                                       "+v"(vC[0]), "+v"(vC[1]), "+v"(vC[2]), "+v"(vC[3]))
+
+    // the fragment registers of a step stay allocated to its end: hipcc otherwise hands a dying fragment's registers to the
+    // exponentials that FOLLOW the asm MFMA reading it (it cannot know that an MFMA reads its operands after it has issued)
+#define W1_KEEP(kN, vC) asm volatile("" :: "v"(kN[0][0]), "v"(kN[0][1]), "v"(kN[1][0]), "v"(kN[1][1]), "v"(vC[0]), "v"(vC[1]), "v"(vC[2]), "v"(vC[3]))
+    auto step_even = [&](auto qk_c, auto nextk_c, int hh) {          // uses K(hh+1) = kfO, V^T(hh) = vfE; fills kfE, vfO
+        constexpr bool DOQK = decltype(qk_c)::value, NEXTK = decltype(nextk_c)::value;
+        W1_LANDED(kfO, vfE);
+        W1_GROUP(0, kfO, vfE, DOQK)
+        W1_RDV(vfO, hh + 1)
+        W1_GROUP(1, kfO, vfE, DOQK)
+        W1_GROUP(2, kfO, vfE, DOQK)
+        if (NEXTK) { enter_tile((hh + 2) >> 1); W1_RDK(kfE, hh + 2) }
+        W1_GROUP(3, kfO, vfE, DOQK)
+        W1_GROUP(4, kfO, vfE, DOQK)
+        W1_GROUP(5, kfO, vfE, DOQK)
+        W1_GROUP(6, kfO, vfE, DOQK)
+        W1_GROUP(7, kfO, vfE, DOQK)
+        W1_KEEP(kfO, vfE);
+    };
+    auto step_odd = [&](auto qk_c, int hh) {                          // uses K(hh+1) = kfE, V^T(hh) = vfO; fills kfO, vfE
+        constexpr bool DOQK = decltype(qk_c)::value;
+        W1_LANDED(kfE, vfO);
+        W1_GROUP(0, kfE, vfO, DOQK)
+        if (DOQK) { W1_RDK(kfO, hh + 2) }
+        W1_GROUP(1, kfE, vfO, DOQK)
+        W1_GROUP(2, kfE, vfO, DOQK)
+        if (DOQK) { W1_RDV(vfE, hh + 1) }
+        W1_GROUP(3, kfE, vfO, DOQK)
+        W1_GROUP(4, kfE, vfO, DOQK)
+        W1_GROUP(5, kfE, vfO, DOQK)
+        W1_GROUP(6, kfE, vfO, DOQK)
+        W1_GROUP(7, kfE, vfO, DOQK)
+        W1_KEEP(kfE, vfO);
+    };
+    constexpr std::true_type Y{};
+    constexpr std::false_type N{};
+    int hs = 0;
+    for (; hs < nhalves - 2; hs += 2) {
+        step_even(Y, Y, hs);
+        step_odd(Y, hs + 1);
+    }
+    step_even(Y, N, hs);                 // the last tile: no further K, no further tile to enter
+    step_odd(N, hs + 1);                 // ... and nothing after its second half
+    __builtin_amdgcn_sched_barrier(0);                       // accumulator MFMAs -> v_accvgpr_read: as above
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the vote: did a probability of the fixed-reference path leave the f32 range?  (attention_wg's test, per 16-query tile)
+    unsigned badmask = 0;
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) badmask |= __any(!(lacc[qf][0] < 1.8446744e19f)) ? (1u << qf) : 0u;
+    if (lane == 0) redo_vote[wave] = (int)badmask;
+    __syncthreads();                                         // also: every wave is done reading the ring (the staging area)
+    const int4 votes = *reinterpret_cast<const int4*>(redo_vote);
+    const bool any_bad = __builtin_amdgcn_readfirstlane(votes.x | votes.y | votes.z | votes.w) != 0;
+
+    // O = O^T / l, head-major inside the output row, through the idle ring so that every store instruction writes 8 whole
+    // 128-byte rows; two passes of 64 queries per wave
+    constexpr int RS = 144;
+    unsigned char* obuf = lds + wave * (64 * RS);
+    unsigned char* rowbase = reinterpret_cast<unsigned char*>(out + ((size_t)b * Nq + q0u) * ldo + h * DH);
+    const unsigned lane_off = ((unsigned)(lane >> 3) * (unsigned)ldo + (unsigned)(lane & 7) * 8u) * 2u;
+    const unsigned rd_off = (unsigned)(lane >> 3) * RS + (unsigned)(lane & 7) * 16u;
+    const unsigned good = any_bad ? ~badmask : ~0u;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int qf = pass * 4 + t;
+            const float inv = 1.0f / lacc[qf][0];
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+                *reinterpret_cast<uint2*>(obuf + (t * 16 + l15) * RS + (df * 16 + g4 * 4) * 2) =
+                    make_uint2(pack_bf16x2(o[df][qf][0] * inv, o[df][qf][1] * inv), pack_bf16x2(o[df][qf][2] * inv, o[df][qf][3] * inv));
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {                     // 8 rows x 128 B per store instruction
+            if ((good >> (pass * 4 + (it >> 1))) & 1u) {
+                const v4u_t v = *reinterpret_cast<const v4u_t*>(obuf + rd_off + it * 8 * RS);
+                v4u_t* dst = reinterpret_cast<v4u_t*>(rowbase + (lane_off + (unsigned)((pass * 64 + it * 8)) * (unsigned)ldo * 2u));
+                __builtin_nontemporal_store(v, dst);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (__builtin_expect(!any_bad, 1)) return;
+
+    // Rare: some 16-query tile overflowed.  The good tiles are stored (above); the two 256-query halves of this workgroup that hold a
+    // bad tile run again as fourth-generation workgroups through the exact path and store exactly those tiles.  Tile t of
+    // fourth-generation wave w in half j is tile (w & 1) * 4 + t of this kernel's wave 2 j + (w >> 1).
+    __syncthreads();                                         // the staging area is the ring
+    const int vv[4] = {votes.x, votes.y, votes.z, votes.w};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (__builtin_amdgcn_readfirstlane(vv[2 * j] | vv[2 * j + 1]) == 0) continue;
+        if (tid == 0) atomicAdd(&g_attn_fallbacks, 1ull);
+        const unsigned mine = ((unsigned)(wave_u < 2 ? vv[2 * j] : vv[2 * j + 1]) >> ((wave_u & 1) * 4)) & 0xfu;
+        attention_wg<true, 4, true>(lds, redo_vote, Q, Kp, Vt, out, ldo, heads, Nq, Nkv, Nkv_pad, bh, qbase + j * 256, mine);
+        __syncthreads();
+    }
+}
+#undef W1_MFMA_QK0
+#undef W1_MFMA_QK1
+#undef W1_MFMA_ACC
+#undef W1_EXP
+#undef W1_PK
+#undef W1_GROUP
+#undef W1_RDK
+#undef W1_RDV
+#undef W1_LANDED
+#undef W1_KEEP
+#undef W1_KADDR
+#undef W1_VADDR
+
 #undef DSRX
 #undef LGKM4
 #undef LGKM2
@@ -545,6 +904,17 @@ int pm_attention_bf16(const void* Q, const void* K, const void* Vt, void* out, i
     const int force = 0;
 #endif
     const long long bh = (long long)B * heads;
+#ifndef PM_ATTN_NO_W1
+    // the one-wave-per-SIMD kernel: whole tiles, at least three of them, whole 512-query workgroups and one or more per CU
+    static const bool w1_on = [] { const char* e = getenv("PMHIP_ATTN_W1"); return true; }();
+    if ((force == 8 || (!force && w1_on && bh * (Nq / W1_QUERIES) >= 256)) && use_exp2 && Nkv % KT == 0 && Nkv / KT >= 3 &&
+        Nq % W1_QUERIES == 0) {
+        const int nqb = Nq / W1_QUERIES;
+        hipLaunchKernelGGL(attention_bf16_w1_kernel, dim3(nqb * B * heads), dim3(THREADS), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
+                           (const bf16_t*)Vt, (bf16_t*)out, ldo, heads, Nq, Nkv, Nkv_pad, nqb);
+        return PMHIP_OK;
+    }
+#endif
     if (force == 4 || (!force && bh * ceil_div(Nq, 256) >= kFill)) launch_qf<4>(Q, K, Vt, out, ldo, B, heads, Nq, Nkv, Nkv_pad, use_exp2, s);
     else if (force == 2 || (!force && bh * ceil_div(Nq, 128) >= kFill)) launch_qf<2>(Q, K, Vt, out, ldo, B, heads, Nq, Nkv, Nkv_pad, use_exp2, s);
     else launch_qf<1>(Q, K, Vt, out, ldo, B, heads, Nq, Nkv, Nkv_pad, use_exp2, s);

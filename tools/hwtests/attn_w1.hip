@@ -1,4 +1,5 @@
-// Same-process A/B of the one-wave-per-SIMD attention kernel (round 6) against the fourth generation at 256 queries per workgroup:
+// Same-process A/B of the one-wave-per-SIMD attention kernel (round 6; shelved: tools/experiments/attention_bf16_w1.hip) against the
+// fourth generation at 256 queries per workgroup (the product's csrc/attention_bf16.hip):
 // bit comparison on ordinary data and through the overflow fallback, then alternating timings.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I paintmind_amd/csrc -o tools/hwtests/attn_w1 tools/hwtests/attn_w1.hip
 //   ./attn_w1 [B H N [rounds]]
@@ -19,41 +20,47 @@ namespace g4 {
 }
 #undef PM_ATTN_FORCE_QF
 #define PM_ATTN_FORCE_QF 8
+#ifdef W1_TIMING_ABL                       // the timed kernel itself ablated (cycles per phase of an ablation)
+#undef ABL
+#define ABL W1_TIMING_ABL
+#endif
 namespace g5 {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
+#include "../experiments/attention_bf16_w1.hip"
 }
+#undef ABL
+#define ABL 0
 #undef PM_ATTN_FORCE_QF
 #ifdef W1_ABLATIONS
 #undef ABL
 #define ABL 1
 #define PM_ATTN_FORCE_QF 8
 namespace g5_noexp {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
+#include "../experiments/attention_bf16_w1.hip"
 }
 #undef ABL
 #define ABL 2
 namespace g5_noreads {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
+#include "../experiments/attention_bf16_w1.hip"
 }
 #undef ABL
 #define ABL 4
 namespace g5_nodma {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
+#include "../experiments/attention_bf16_w1.hip"
 }
 #undef ABL
 #define ABL 8
 namespace g5_nobar {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
+#include "../experiments/attention_bf16_w1.hip"
 }
 #undef ABL
 #define ABL 12
 namespace g5_nodmabar {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
+#include "../experiments/attention_bf16_w1.hip"
 }
 #undef ABL
 #define ABL 15
 namespace g5_skel {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
+#include "../experiments/attention_bf16_w1.hip"
 }
 #undef ABL
 #define ABL 0
@@ -61,6 +68,9 @@ namespace g5_skel {
 #endif
 #ifdef W1_VARIANT
 #define PM_ATTN_FORCE_QF 8
+#ifdef W1_VARIANT_DEF
+#define W1_VARIANT_DEF_ON 1
+#endif
 namespace g5b {
 #include W1_VARIANT
 }
@@ -88,42 +98,6 @@ int main(int argc, char** argv) {
     (void)hipMalloc(&q, n * 2); (void)hipMalloc(&k, n * 2); (void)hipMalloc(&v, n * 2); (void)hipMalloc(&o, n * 2); (void)hipMalloc(&oref, n * 2);
     hipMemcpy(q, hq.data(), n * 2, hipMemcpyHostToDevice); hipMemcpy(v, hv.data(), n * 2, hipMemcpyHostToDevice);
     V vs[] = {{"gen4 (256 queries / WG)", g4::pm_attention_bf16, 0}, {"gen5 (one wave per SIMD)", g5::pm_attention_bf16, 0},
-#ifdef W1_ABLATIONS
-#undef ABL
-#define ABL 1
-#define PM_ATTN_FORCE_QF 8
-namespace g5_noexp {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
-}
-#undef ABL
-#define ABL 2
-namespace g5_noreads {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
-}
-#undef ABL
-#define ABL 4
-namespace g5_nodma {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
-}
-#undef ABL
-#define ABL 8
-namespace g5_nobar {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
-}
-#undef ABL
-#define ABL 12
-namespace g5_nodmabar {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
-}
-#undef ABL
-#define ABL 15
-namespace g5_skel {
-#include "../../paintmind_amd/csrc/attention_bf16.hip"
-}
-#undef ABL
-#define ABL 0
-#undef PM_ATTN_FORCE_QF
-#endif
 #ifdef W1_VARIANT
               {"gen5 variant", g5b::pm_attention_bf16, 0},
 #endif
@@ -189,5 +163,33 @@ namespace g5_skel {
             x.us += ms * 1e3 / reps / rounds;
         }
     for (auto& x : vs) printf("%-28s %8.1f us  %7.1f TFLOP/s\n", x.name, x.us, 4.0 * N * N * 64 * B * H / x.us / 1e6);
+    {   // the same kernels writing a head-major output [B * H, N, 64] (heads = 1, ldo = 64: 16 KiB contiguous per 128 queries
+        // instead of 128-byte pieces at a 1 KiB stride): what the output layout costs
+        for (auto& x : vs) x.us = 0;
+        for (int round = 0; round < rounds; ++round)
+            for (auto& x : vs) {
+                for (int i = 0; i < 3; ++i) x.fn(q, k, v, o, 64, B * H, 1, N, N, N, 1, 0);
+                hipEventRecord(e0, 0);
+                const int reps = 20;
+                for (int i = 0; i < reps; ++i) x.fn(q, k, v, o, 64, B * H, 1, N, N, N, 1, 0);
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                x.us += ms * 1e3 / reps / rounds;
+            }
+        for (auto& x : vs) printf("%-28s %8.1f us  %7.1f TFLOP/s   (head-major output)\n", x.name, x.us, 4.0 * N * N * 64 * B * H / x.us / 1e6);
+    }
+#ifdef PM_ATTN_W1_TIMING
+    {   // cycles per phase of the one-wave-per-SIMD kernel, per wave (one launch)
+        unsigned long long z[8] = {0}, t[8];
+        hipMemcpyToSymbol(HIP_SYMBOL(g5::g_w1_times), z, sizeof z);
+        g5::pm_attention_bf16(q, k, v, o, H * 64, B, H, N, N, N, 1, 0);
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(t, HIP_SYMBOL(g5::g_w1_times), sizeof t);
+        const double w = (double)t[0];
+        printf("gen5 cycles per (wave, item): start (cold: Q + tile 0; warm: ~0) %.0f, first half-tile %.0f, loop %.0f (%.1f per half-tile step, MFMA floor 1152), "
+               "seam (vote, O -> LDS) %.0f; final flush per wave %.0f; pairs %llu\n",
+               t[1] / w, t[2] / w, t[3] / w, t[3] / w / (N / 32), t[4] / w, t[5] / (double)(256 * 4), t[0]);
+    }
+#endif
     return 0;
 }
