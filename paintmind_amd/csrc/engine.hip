@@ -257,10 +257,14 @@ struct Switches {
         w.blocking_wait = e && atoi(e) != 0;
         e = getenv("PMHIP_DECODE_OVERLAP_MAX_ROWS");
         if (e) w.overlap_rows = atoi(e);
+        e = getenv("PMHIP_LOGITS_STATS");
+        w.logits_stats = !(e && atoi(e) == 0);
         return w;
     }
     int fold_rows_cap = 0;  // PMHIP_FOLD_MAX_ROWS (development / tests): cap on the rows one folded launch takes, see fold_rows()
     bool center = true;     // PMHIP_HILO_CENTER=0: the residual producers do not centre the hi plane (A/B, tests)
+    bool logits_stats = true;     // PMHIP_LOGITS_STATS=0 (A/B): the logits GEMM leaves no block statistics, the sampling kernel derives
+                                  // them from the rows it then has to read in full (same ids and scores, bit for bit)
     bool blocking_wait = false;   // PMHIP_BLOCKING_WAIT=1: host waits between decode-loop segments sleep instead of spinning
     int key() const { return (hilo ? 2 : 0) + (fold ? 1 : 0) + (stats ? 4 : 0) + (center ? 8 : 0); }
 };
@@ -822,7 +826,7 @@ int step_tower(pmhip_s2* s2, const int64_t* ids, int B, hipStream_t s, const flo
     // softmax statistics of the logits' 64-column blocks for the sampling kernel: from the logits GEMM, or -- guided -- from the
     // combination, which produces the logits that are sampled
     float* lstats = nullptr;
-    if (c.n_embed % 64 == 0) WS(s2->ws, "s2.lstats", (size_t)M * (c.n_embed / 64) * 8, lstats);
+    if (c.n_embed % 64 == 0 && s2->sw.logits_stats) WS(s2->ws, "s2.lstats", (size_t)M * (c.n_embed / 64) * 8, lstats);
     PM_TRY(s2_tower(s2, tp, B, logits, s, true, guidance ? nullptr : lstats));
     if (guidance) {
         float* uncond;
@@ -852,7 +856,7 @@ int step_tail(pmhip_s2* s2, pmhip_vqgan* vq, int64_t* ids, int B, int topk, floa
     WS(s2->ws, "s2.pred", (size_t)M * 8, pred);
     WS(s2->ws, "s2.score", (size_t)M * 4, score);
     float* lstats = nullptr;                                 // step_tower filled them (same condition, same workspace entry)
-    if (c.n_embed % 64 == 0) WS(s2->ws, "s2.lstats", (size_t)M * (c.n_embed / 64) * 8, lstats);
+    if (c.n_embed % 64 == 0 && s2->sw.logits_stats) WS(s2->ws, "s2.lstats", (size_t)M * (c.n_embed / 64) * 8, lstats);
     PM_TRY(pm_sample_rows(logits, c.n_embed, lstats, ids, (int64_t)c.n_embed, topk, temperature, noise, seed, step,
                           image_base * (uint64_t)c.tokens, pred, ids, score, M, c.n_embed, gp, s));
     if (img_out) PM_TRY(decode_pred(s2, vq, B, img_out, s));
