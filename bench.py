@@ -220,7 +220,7 @@ def work_per_step(workload, decode_every_step=True, kinds=None):
     # bytes the sampling kernel reads per row: the block statistics (8 B per 64 columns) + the top-k blocks (256 B each) where the
     # tile sampler runs (top-k <= 8, V % 64 == 0: sample.hip), else the whole fp32 row
     V, k = vq["n_embed"], 5
-    tiles = V % 64 == 0 and k <= 8 and os.environ.get("PMHIP_SAMPLE_TILES", "1") != "0"
+    tiles = V % 64 == 0 and k <= 8
     return B * (T * gs + n_dec * gd), B * (T * as_ + n_dec * ad), B * T * N * ((V // 64) * 8 + k * 256 if tiles else V * 4)
 
 

@@ -496,12 +496,6 @@ __global__ __launch_bounds__(THREADS, 2) void attention_kernel(const T* __restri
 #undef DSRX
 #undef LGKM_N
 
-// A/B switch while the third-generation bf16 kernel (attention_bf16.hip) is being measured: PMHIP_ATTN_OLD=1
-bool old_bf16_kernel() {
-    static const int v = [] { const char* e = getenv("PMHIP_ATTN_OLD"); return e ? atoi(e) : 0; }();   // read once, thread-safe
-    return v != 0;
-}
-
 }  // namespace
 
 int pm_attention_bf16(const void* Q, const void* K, const void* Vt, void* out, int ldo, int B, int heads, int Nq, int Nkv,
@@ -527,17 +521,8 @@ extern "C" int pmhip_attention(int dtype, const void* Q, const void* K, const vo
         else
             hipLaunchKernelGGL((attention_kernel<float, false, 2>), grid, block, 0, s, (const float*)Q, (const float*)K,
                                (const float*)Vt, (float*)out, ldo, heads, Nq, Nkv, Nkv_pad, nqb);
-    } else if (!old_bf16_kernel()) {
-        PM_TRY(pm_attention_bf16(Q, K, Vt, out, ldo, B, heads, Nq, Nkv, Nkv_pad, use_exp2, s));
     } else {
-        const int nqb = ceil_div(Nq, 4 * 4 * 16);
-        dim3 grid(nqb * B * heads);
-        if (use_exp2)
-            hipLaunchKernelGGL((attention_kernel<bf16_t, true, 4>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K,
-                               (const bf16_t*)Vt, (bf16_t*)out, ldo, heads, Nq, Nkv, Nkv_pad, nqb);
-        else
-            hipLaunchKernelGGL((attention_kernel<bf16_t, false, 4>), grid, block, 0, s, (const bf16_t*)Q, (const bf16_t*)K,
-                               (const bf16_t*)Vt, (bf16_t*)out, ldo, heads, Nq, Nkv, Nkv_pad, nqb);
+        PM_TRY(pm_attention_bf16(Q, K, Vt, out, ldo, B, heads, Nq, Nkv, Nkv_pad, use_exp2, s));
     }
     PM_HIP(hipGetLastError());
     return PMHIP_OK;

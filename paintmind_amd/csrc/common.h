@@ -311,5 +311,19 @@ __device__ __forceinline__ float2 softmax_block_stat(float a, float b, float c, 
     return make_float2(m, s);
 }
 
+// DEVELOPMENT KNOBS: tuning values and the switches of finished A/Bs (tools/*.sh sweep them).  They are read from the environment
+// only in a development build (PM_EXTRA_FLAGS=-DPM_DEV_KNOBS bash paintmind_amd/csrc/build.sh); the product library carries the
+// defaults as constants -- no configuration that no test runs (round-5 review, W6).  The switches the tests DO exercise stay
+// runtime: PMHIP_HILO, PMHIP_LN_UNFOLD, PMHIP_LN_STATS, PMHIP_HILO_CENTER, PMHIP_FOLD_MAX_ROWS (engine.hip Switches).
+static inline int pm_dev_knob(const char* name, int dflt) {
+#ifdef PM_DEV_KNOBS
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t dtype_size(int dtype) { return dtype == PMHIP_BF16 ? 2 : 4; }

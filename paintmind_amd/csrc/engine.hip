@@ -257,13 +257,12 @@ struct Switches {
         w.blocking_wait = e && atoi(e) != 0;
         e = getenv("PMHIP_DECODE_OVERLAP_MAX_ROWS");
         if (e) w.overlap_rows = atoi(e);
-        e = getenv("PMHIP_LOGITS_STATS");
-        w.logits_stats = !(e && atoi(e) == 0);
+        w.logits_stats = pm_dev_knob("PMHIP_LOGITS_STATS", 1) != 0;
         return w;
     }
     int fold_rows_cap = 0;  // PMHIP_FOLD_MAX_ROWS (development / tests): cap on the rows one folded launch takes, see fold_rows()
     bool center = true;     // PMHIP_HILO_CENTER=0: the residual producers do not centre the hi plane (A/B, tests)
-    bool logits_stats = true;     // PMHIP_LOGITS_STATS=0 (A/B): the logits GEMM leaves no block statistics, the sampling kernel derives
+    bool logits_stats = true;     // PMHIP_LOGITS_STATS=0 (development builds, profiles/r06_d): the logits GEMM leaves no block statistics, the sampling kernel derives
                                   // them from the rows it then has to read in full (same ids and scores, bit for bit)
     bool blocking_wait = false;   // PMHIP_BLOCKING_WAIT=1: host waits between decode-loop segments sleep instead of spinning
     int key() const { return (hilo ? 2 : 0) + (fold ? 1 : 0) + (stats ? 4 : 0) + (center ? 8 : 0); }

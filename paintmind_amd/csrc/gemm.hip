@@ -275,10 +275,7 @@ int launch(const GemmParams& p, hipStream_t s) {
 
 // process-wide development switches: read once, in the thread-safe initialiser of a function-local static (the first GEMMs of
 // a process are launched from several lane threads at the same time)
-int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
+int env_int(const char* name, int dflt) { return pm_dev_knob(name, dflt); }      // development builds only (common.h)
 
 // A folded GEMM (set_lnfold: M, N multiples of 256) runs on the 128x128 kernel while the 256x256 tiling would leave at least half
 // of the CUs without a workgroup: 4x the workgroups, a quarter of the serial K loop each, bit-identical results.

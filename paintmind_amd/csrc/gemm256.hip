@@ -328,8 +328,8 @@ __global__ __launch_bounds__(THREADS) void gemm256_kernel(const GemmParams p) {
     }
 }
 
-// Process-wide tuning knobs of this kernel (development: tools/chunk_sweep.sh, tools/env_sweep.sh), read from the environment
-// exactly ONCE, under std::call_once: the first launches of a process come from several lane threads at the same time.
+// Process-wide tuning knobs of this kernel (development builds only, common.h pm_dev_knob: tools/chunk_sweep.sh, tools/env_sweep.sh),
+// read exactly ONCE, under std::call_once: the first launches of a process come from several lane threads at the same time.
 struct Knobs256 {
     int chunk = 6;          // PMHIP_CHUNK256: width of the L2-aware tile walk
     int persist = 256;      // PMHIP_PERSIST256: workgroups of the persistent grid (0 = one per tile)
@@ -339,9 +339,9 @@ const Knobs256& knobs256() {
     static Knobs256 k;
     static std::once_flag once;
     std::call_once(once, [] {
-        if (const char* e = getenv("PMHIP_CHUNK256")) k.chunk = atoi(e);
-        if (const char* e = getenv("PMHIP_PERSIST256")) k.persist = atoi(e);
-        if (const char* e = getenv("PMHIP_G256_RES_KMIN")) k.res_kmin = atoi(e);
+        k.chunk = pm_dev_knob("PMHIP_CHUNK256", k.chunk);
+        k.persist = pm_dev_knob("PMHIP_PERSIST256", k.persist);
+        k.res_kmin = pm_dev_knob("PMHIP_G256_RES_KMIN", k.res_kmin);
     });
     return k;
 }

@@ -146,8 +146,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm2b_kernel(const GemmParams p) 
 
 template <int EPI, typename OutT>
 int launch2b(const GemmParams& p0, hipStream_t s) {
-    // PMHIP_CHUNK2B (development): read once, in the thread-safe initialiser of a function-local static
-    static const int g_chunk2b = [] { const char* e = getenv("PMHIP_CHUNK2B"); return e ? atoi(e) : 12; }();
+    // PMHIP_CHUNK2B (development builds, common.h pm_dev_knob): read once, in the thread-safe initialiser of a function-local static
+    static const int g_chunk2b = pm_dev_knob("PMHIP_CHUNK2B", 12);
     GemmParams p = p0;
     p.chunk = g_chunk2b;
     const int tiles = (p.M / BM) * (p.N / BN);

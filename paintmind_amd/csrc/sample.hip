@@ -415,13 +415,7 @@ __global__ __launch_bounds__(THREADS) void remask_reg_kernel(int64_t* __restrict
 
 }  // namespace
 
-static int sample_env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    if (!v || !*v) return dflt;
-    char* end = nullptr;
-    const long x = strtol(v, &end, 10);
-    return (end && *end == 0) ? (int)x : dflt;
-}
+static int sample_env_int(const char* name, int dflt) { return pm_dev_knob(name, dflt); }     // development builds only (common.h)
 
 int pm_sample_rows(const float* logits, int ldl, const float* block_stats, const int64_t* ids_in, int64_t mask_id, int topk,
                    float temperature, const float* noise, uint64_t seed, uint32_t step, uint64_t row_base, int64_t* pred_out,

@@ -3,6 +3,7 @@
 #   gpurun -- 'bash tools/ab_env.sh PMHIP_ATTN_PLANES "1 0" [rounds] [extra bench args]'
 # Every arm differs in the thing the conclusion is about: name the switch, list its values.
 set -u
+# (a development knob needs a development build first: PM_EXTRA_FLAGS=-DPM_DEV_KNOBS bash paintmind_amd/csrc/build.sh)
 var=$1; vals=$2; rounds=${3:-3}; shift; shift; shift || true
 for r in $(seq 1 $rounds); do
   for v in $vals; do
