@@ -149,3 +149,19 @@ def test_missing_extension_fails_loudly(monkeypatch):
     with pytest.raises(_lib.PmhipError) as e:
         _lib.load()
     assert "no CPU fallback" in str(e.value) or "not built" in str(e.value)
+
+
+def test_product_library_reads_only_the_runtime_switches_the_tests_exercise():
+    """Round 6: tuning knobs and the switches of finished A/Bs are compiled into the library as constants (common.h pm_dev_knob;
+    the sweep scripts under tools/ use a -DPM_DEV_KNOBS build).  What the shipped library still reads from the environment is this
+    list, each of them exercised by a test (PMHIP_HILO / PMHIP_LN_UNFOLD / PMHIP_LN_STATS / PMHIP_HILO_CENTER / PMHIP_FOLD_MAX_ROWS:
+    tests/test_gpu_model.py and test_gpu_ops.py; AMD_DIRECT_DISPATCH: tests/test_gpu_dist.py) or documented in include/pmhip.h
+    (PMHIP_BLOCKING_WAIT, PMHIP_DECODE_OVERLAP_MAX_ROWS)."""
+    import re
+    import subprocess
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "paintmind_amd", "libpaintmind_hip.so")
+    out = subprocess.run(["strings", "-n", "6", lib], capture_output=True, text=True, timeout=120).stdout
+    names = set(re.findall(r"\b(PMHIP_[A-Z0-9_]+|AMD_DIRECT_DISPATCH)\b", out)) - {"PMHIP_H"}
+    allowed = {"AMD_DIRECT_DISPATCH", "PMHIP_BLOCKING_WAIT", "PMHIP_DECODE_OVERLAP_MAX_ROWS", "PMHIP_FOLD_MAX_ROWS", "PMHIP_HILO",
+               "PMHIP_HILO_CENTER", "PMHIP_LN_STATS", "PMHIP_LN_UNFOLD"}
+    assert names <= allowed, sorted(names - allowed)
