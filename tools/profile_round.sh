@@ -9,7 +9,9 @@ export TMPDIR=/tmp
 out=gpurun_out/$tag
 rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $out/stats.log 2>&1
-PM_BENCH_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o r -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $out/stats1.log 2>&1
+# one lane AND no side-stream decode (PMHIP_DECODE_OVERLAP_MAX_ROWS=0): a single lane otherwise runs each step's ViT decode beside the next
+# step's tower (round 5), and kernels that share the chip report inflated durations (r06_z: attention 168 instead of 132 us per launch)
+PM_BENCH_STREAMS=1 PMHIP_DECODE_OVERLAP_MAX_ROWS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o r -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $out/stats1.log 2>&1
 PM_BENCH_NO_GRAPH=1 PM_BENCH_STREAMS=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $out/pmc_fetch.log 2>&1
 PM_BENCH_NO_GRAPH=1 PM_BENCH_STREAMS=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > $out/pmc_write.log 2>&1
 PM_BENCH_NO_GRAPH=1 PM_BENCH_STREAMS=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_util -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extra > $out/pmc_util.log 2>&1
