@@ -3,7 +3,7 @@ development container only -- see _ref_import.py).  The fixtures are data: seede
 reference's outputs.  Run:  python tests/golden/make_goldens.py
 
 F1  tiny_vqgan.npz / tiny_pipeline.npz / tiny_forward.npz : tiny configs, weights + inputs + intermediates
-F2  full_vqgan.npz / full_stage2.npz / full_stage2_d768.npz / full_stage2_d1024.npz : full-size configs; weights are NOT stored -- both sides
+F2  full_vqgan.npz / full_vqgan_b512.npz / full_stage2.npz / full_stage2_d768.npz / full_stage2_d1024.npz : full-size configs; weights are NOT stored -- both sides
     re-create them with torch.manual_seed(seed) + create_model (bit-identical init, checked by sha256)
 F3  api.json                            : API-behaviour facts (shapes, dtypes, list lengths, errors)
 """
@@ -313,6 +313,28 @@ def full_stage2():
     return {"full_stage2_weights_sha256": sha}
 
 
+def full_vqgan_b512():
+    """BASELINE cfg 5's stage 1 as this build assumes it (the reference defines no vit-b-vqgan; image 512,
+    patch 16, dim 768, depth 12, heads 12, mlp 3072, 8192 x 32 codebook): the reference's own classes run on that config, B = 1."""
+    ref_cfg["vit-b-vqgan-512"] = my_cfg["vit-b-vqgan-512"]
+    torch.manual_seed(0)
+    m = ref.create_model(arch="vqgan", version="vit-b-vqgan-512", pretrained=False).eval()
+    sha = sd_sha(m)
+    x = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(101)) * 2 - 1
+    z, loss, idx = m.encode(x)
+    ze = m.prev_quant(m.encoder(x))
+    zn = torch.nn.functional.normalize(ze, dim=-1).view(-1, 32)
+    en = torch.nn.functional.normalize(m.quantize.embedding.weight, dim=-1)
+    d = torch.sum(zn ** 2, dim=1, keepdim=True) + torch.sum(en ** 2, dim=1) - 2 * torch.einsum("bd,nd->bn", zn, en)
+    top2 = torch.topk(d, 2, dim=1, largest=False).values
+    rec = m.decode(z)
+    save("full_vqgan_b512.npz", idx=idx.numpy().astype(np.int16), gap=(top2[:, 1] - top2[:, 0]).numpy(), z=z.numpy(),
+         prev_quant=ze.numpy(), loss=loss.numpy(), rec_sub=rec[:, :, ::8, ::8].numpy(),
+         rec_clamped_frac=np.array((rec.abs() == 1).float().mean().item(), dtype=np.float32),
+         weights_sha=np.frombuffer(bytes.fromhex(sha), dtype=np.uint8))
+    return {"full_vqgan_b512_weights_sha256": sha}
+
+
 def full_stage2_text(key, out_name, img_stride):
     """The text-conditioned BASELINE configs at full size, B = 1: cfg 4 = vit-s-vqgan + 24L/d768 with a (77, 768) context
     (width 768 == dim: context_proj is Identity, transformer.py:58) -- the model north_star's target is quoted on -- and cfg 5 =
@@ -347,7 +369,17 @@ def full_stage2_text(key, out_name, img_stride):
     ids1, img1 = pipe.sample(ids0.clone(), np.float64(0.4), text=ctx, topk=1, temperature=1.0)
     lse = torch.logsumexp(logits, -1)
     top2 = torch.topk(logits, 2, dim=-1).values
-    save(out_name, ids0=ids0.numpy().astype(np.int16), context=ctx.numpy(), logits_sub=logits[:, ::8, ::64].numpy(),
+    # the same step with topk = 5 and a temperature, under the noise the reference draws (generate.py:41): only the k candidates of
+    # a row can win (generate.py:33-37), so the fixture keeps the noise at the reference's top-5 columns -- 5 floats per row instead
+    # of 8192 -- and the test rebuilds a noise tensor that is 0.5 everywhere else
+    torch.manual_seed(77)
+    with CaptureUniform() as cap:
+        ids5, _ = pipe.sample(ids0.clone(), np.float64(0.4), text=ctx, topk=5, temperature=0.7)
+    (noise,) = [t for t in cap.rec if t.shape == (1, N, V)]
+    top5 = torch.topk(logits, 5, dim=-1)
+    extra = dict(s5_cols=top5.indices.numpy().astype(np.int16), s5_noise=noise.gather(2, top5.indices).numpy(), s5_ids=ids5.numpy().astype(np.int16),
+                 s5_gap56=(torch.topk(logits, 6, dim=-1).values[..., 4] - torch.topk(logits, 6, dim=-1).values[..., 5]).numpy())
+    save(out_name, **extra, ids0=ids0.numpy().astype(np.int16), context=ctx.numpy(), logits_sub=logits[:, ::8, ::64].numpy(),
          logits_argmax=logits.argmax(-1).numpy().astype(np.int16), logits_lse=lse.numpy(),
          logits_top2gap=(top2[..., 0] - top2[..., 1]).numpy(), ids1=ids1.numpy().astype(np.int16),
          img1_sub=img1[:, :, ::img_stride, ::img_stride].numpy(),
@@ -357,7 +389,7 @@ def full_stage2_text(key, out_name, img_stride):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tiny_vqgan", "tiny_pipeline", "tiny_forward", "full_vqgan", "full_stage2", "full_stage2_d768",
-                             "full_stage2_d1024"]
+                             "full_stage2_d1024", "full_vqgan_b512"]
     api_path = os.path.join(HERE, "api.json")
     api = json.load(open(api_path)) if os.path.exists(api_path) else {}
     api["torch_version"] = torch.__version__
@@ -371,6 +403,8 @@ if __name__ == "__main__":
         api.update(full_vqgan())
     if "full_stage2" in which:
         api.update(full_stage2())
+    if "full_vqgan_b512" in which:
+        api.update(full_vqgan_b512())
     if "full_stage2_d768" in which:
         api.update(full_stage2_text("bench-text-24L-d768", "full_stage2_d768.npz", 4))
     if "full_stage2_d1024" in which:

@@ -192,6 +192,32 @@ def test_north_star_size_models_weights_and_oracle_against_the_reference(key, na
     assert np.all(d["logits_top2gap"][bad] < 1e-4)
 
 
+def test_vit_b_512_weights_and_oracle_against_the_reference():
+    """cfg 5's assumed stage 1 (vit-b-vqgan-512): seeded weights sha-identical to the reference's, and the torch port of the oracle
+    reproduces the reference's tokens and reconstruction (tests/golden/full_vqgan_b512.npz)."""
+    import hashlib
+    import torch
+    import paintmind_amd as pm
+    from oracle import torch_port as TP
+    from util import api_facts
+    _, d = load_golden("full_vqgan_b512.npz")
+    torch.manual_seed(0)
+    m = pm.create_model(arch="vqgan", version="vit-b-vqgan-512", pretrained=False).eval()
+    h = hashlib.sha256()
+    for k, v in m.state_dict().items():
+        h.update(k.encode())
+        h.update(v.numpy().tobytes())
+    assert h.hexdigest() == api_facts()["full_vqgan_b512_weights_sha256"] == bytes(d["weights_sha"]).hex()
+    sd = dict(m.state_dict())
+    x = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(101)) * 2 - 1
+    with torch.no_grad():
+        z, loss, idx = TP.vqgan_encode(x, sd, vq_cfg("vit-b-vqgan-512"))
+        mism = idx.numpy().reshape(-1) != d["idx"].reshape(-1)
+        assert mism.sum() <= 2 and np.all(d["gap"][mism] < 1e-5)
+        rec = TP.vqgan_decode(torch.from_numpy(d["z"]), sd, vq_cfg("vit-b-vqgan-512"))
+    assert maxabs(rec.numpy()[:, :, ::8, ::8], d["rec_sub"]) < 1e-4
+
+
 # ---- masked-token objective, forward only (generate.py:78-146) ---------------------------------------
 @pytest.fixture(scope="module")
 def tf():
