@@ -201,6 +201,9 @@ struct TowerBufs {
     // centred hi plane (gemm_common.h, GemmParams::center_coef): the producers subtract the row mean the last LayerNorm saw
     bool center = false;        // mode on (fold on and not PMHIP_HILO_CENTER=0)
     bool coef_valid = false;    // coef holds the statistics of the CURRENT hi plane (set by tower_coef, cleared by a producer)
+    bool coef_deferred = false; // ... but nobody has WRITTEN them yet: tower_coef left that to the first folded consumer, which
+                                // materialises them from `parts` (fold_desc hands it the parts and clears this flag).  A reader of
+                                // coef -- the centred producer -- refuses to run while it is set (round-5 advisor: the invariant was implicit)
     float* shift = nullptr;     // per-row running sum of the subtracted means: only where the absolute x is needed again (ViT encoder)
     bool hilo = false;      // bf16 mode
     int fold_rows_cap = 0;  // Switches::fold_rows_cap
@@ -322,6 +325,7 @@ int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W
         b.parts_valid = b.fold && N % 64 == 0 && N <= 1024 && b.stats;   // pmhip_ln_coef_parts combines <= 16 parts
         const bool self = r.hi == b.xh && r.rows == 0;                 // x += ... (not the GEMM that opens the stream)
         const float* cc = (b.center && self && b.coef_valid) ? b.coef : nullptr;
+        PM_REQUIRE(!cc || !b.coef_deferred, "residual_gemm: the fold coefficients of this LayerNorm were left to a folded consumer that never ran");
         const int shift_mode = !b.shift ? 0 : (self ? (cc ? 2 : 0) : 1);
         b.coef_valid = false;                                          // the hi plane changes
         if (cc || b.shift)
@@ -338,14 +342,17 @@ int residual_gemm(int dtype, TowerBufs& b, const void* A, int lda, const void* W
 // pmhip_ln_coef_parts in front of it otherwise) and nothing is launched here; else the pass over the plane.
 int tower_coef(TowerBufs& b, int M, int dim, hipStream_t s) {
     b.coef_valid = true;
+    b.coef_deferred = b.parts_valid;
     if (b.parts_valid) return PMHIP_OK;
     return pmhip_ln_coef(b.xh, 1e-5f, b.coef, M, dim, s);
 }
 // the fold descriptor of the rows [m0, ...) of the tower
-pmhip_lnfold fold_desc(const TowerBufs& b, int m0, int dim, const float* c, const float* d) {
+// the ONLY place a fold descriptor is built: a consumer handed a descriptor without `parts` would read coefficients nobody wrote
+pmhip_lnfold fold_desc(TowerBufs& b, int m0, int dim, const float* c, const float* d) {
     pmhip_lnfold ln{};
     ln.coef = b.coef + (size_t)m0 * 2; ln.c = c; ln.d = d;
     if (b.parts_valid) { ln.parts = b.parts + (size_t)m0 * (dim / 64) * 2; ln.nparts = dim / 64; ln.eps = 1e-5f; }
+    b.coef_deferred = false;                                  // the consumer about to be launched writes coef (from parts) or finds it written
     return ln;
 }
 
