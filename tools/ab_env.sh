@@ -9,7 +9,7 @@ for r in $(seq 1 $rounds); do
   for v in $vals; do
     env $var=$v python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra "$@" 2>/dev/null | tail -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); f = d['kernel_families']
+d = json.loads(sys.stdin.read()); f = d.get('kernel_families', {})
 print('$var=$v', d['value'], d['ms_per_step'], d['self_check'], ' '.join(f'{k} {round(x[\"ms\"], 2)}' for k, x in f.items() if x['launches']))"
   done
 done
