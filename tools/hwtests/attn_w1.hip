@@ -67,7 +67,10 @@ namespace g5_skel {
 #undef PM_ATTN_FORCE_QF
 #endif
 #ifdef W1_VARIANT
-#define PM_ATTN_FORCE_QF 8
+#ifndef W1_VARIANT_QF
+#define W1_VARIANT_QF 8
+#endif
+#define PM_ATTN_FORCE_QF W1_VARIANT_QF
 #ifdef W1_VARIANT_DEF
 #define W1_VARIANT_DEF_ON 1
 #endif
