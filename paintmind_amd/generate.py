@@ -347,7 +347,7 @@ class Pipeline(nn.Module):
         return torch.cuda.Stream(device=device)
 
     def generate_ids(self, context, B, timesteps, temperature, topk, decode_flags, seed, image_base=0, use_graph=False, streams=1,
-                     join=True, wait_current=True, host=None, guidance_scale=None):
+                     join=True, wait_current=True, host=None, guidance_scale=None, ids0=None):
         """The decode loop on device tensors: returns (ids [B,N], imgs [n_decoded,B,C,H,W] or None).
 
         streams > 1 (or a tuple of micro-batch sizes): the batch is cut into contiguous micro-batches that run CONCURRENTLY on separate HIP
@@ -359,7 +359,8 @@ class Pipeline(nn.Module):
         (only valid when `context` is None or was produced before the lanes last synchronised with it).
         host = (pinned [n_decoded, B, C, H, W] float32 tensor, [copy stream per lane]): the decoded images go straight to
         the host buffer (every lane fills its rows, each image as soon as it is complete, on its own copy stream); no
-        device image tensor is returned."""
+        device image tensor is returned.
+        ids0 (streams = 1 only): start from these ids [B, N] int64 instead of the all-mask state (the region loops of inpaint / outpaint)."""
         eng = self.engine()
         temps, nmask = self._schedule(timesteps, temperature)
         if isinstance(streams, (list, tuple)):           # explicit micro-batch sizes, e.g. (32, 16, 16)
@@ -377,8 +378,11 @@ class Pipeline(nn.Module):
                 # Re-measured with the round-5 kernels (profiles/r05_g_*): equal lanes are within +-1 % of this end to end on
                 # every workload and box tried (and the per-launch attention time in the bench's brackets is the same): kept.
                 bounds = [(0, B // 2 + 1), (B // 2 + 1, B)]
+        if ids0 is not None and streams != 1:
+            raise ValueError("generate_ids: ids0 needs streams=1")
         if streams == 1:
-            ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device)
+            ids = torch.full((B, self.num_tokens), self.mask_token_id, dtype=torch.long, device=eng.device) if ids0 is None \
+                else ids0.to(eng.device, torch.long).clone()
             return eng.generate(self.vqgan.engine(), ids, context, temps, nmask, decode_flags, topk, seed=seed,
                                 image_base=image_base, use_graph=use_graph,
                                 host=None if host is None else (host[0], 0, host[1][0]), want_device_imgs=host is None,
@@ -549,6 +553,17 @@ class Pipeline(nn.Module):
         # the reference builds this with float arithmetic (ids*mask + id*(1-mask), generate.py:210,229),
         # which yields a float tensor that nn.Embedding rejects; the intended integer result is used here
         ids = torch.where(keep, ids, torch.full_like(ids, self.mask_token_id))
+        if timesteps >= 2 and not self._on_cpu():
+            # more than the reference's default single step: the native decode loop (graph replay by default, like generate()) from
+            # these start ids, decoding only the last step -- bit-identical to the per-step composition below (tests/test_gpu_model.py)
+            use_graph = os.environ.get("PMHIP_GENERATE_GRAPH", "1") != "0"
+            ids, imgs = self.generate_ids(text, ids.shape[0], timesteps, temperature, topk, [False] * (timesteps - 1) + [True], seed,
+                                          use_graph=use_graph, streams=1, ids0=ids)
+            return (imgs[0], ids) if return_ids else imgs[0]
+        return self._region_steps(ids, text, timesteps, topk, temperature, seed, return_ids)
+
+    def _region_steps(self, ids, text, timesteps, topk, temperature, seed, return_ids=False):
+        """the region loop as the reference writes it: one sample() per step (generate.py:211-216,230-235)"""
         out = None
         for step in range(timesteps):
             progress = (step + 1) / timesteps

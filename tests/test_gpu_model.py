@@ -454,6 +454,16 @@ def test_inpaint_outpaint_match_oracle_composition(tiny_pipe):
     b = pipe.inpaint(t(x[:1]), (0, 0, 32, 32), timesteps=2, topk=8, temperature=2.0)
     c2 = pipe.inpaint(t(x[:1]), (0, 0, 32, 32), timesteps=2, topk=8, temperature=2.0)
     assert torch.equal(a, b) and not torch.equal(a, c2)
+    # more than one step runs the NATIVE decode loop from the region's start ids (graph replay by default; round 6): bit for bit the
+    # per-step composition the reference writes (one sample() per step), sampled steps included, eager and replayed
+    z, ids0, _ = pipe.to_latent(t(x), None)
+    ids0[:, 3:9] = pipe.mask_token_id
+    for rep in range(3):                                       # eager warm-up of the graph path, capture, replay
+        img_n, ids_n = None, None
+        ids_n, imgs = pipe.generate_ids(None, ids0.shape[0], 3, 2.0, 4, [False, False, True], 99, use_graph=True, streams=1, ids0=ids0)
+        img_c, ids_c = pipe._region_steps(ids0.clone(), None, 3, 4, 2.0, 99, return_ids=True)
+        assert torch.equal(ids_n, ids_c) and torch.equal(imgs[0], img_c), rep
+    assert int((ids0 == pipe.mask_token_id).sum()) == 6 * ids0.shape[0]          # the caller's start ids are not modified
 
 
 # ------------------------------------------------------------------------------------------------
