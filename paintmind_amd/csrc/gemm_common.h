@@ -295,6 +295,9 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4_t (&acc
         }
     }
 
+#ifdef PM_ABL_EPI_SKIP                       // timing ablation (tools/epilogue_cost.py): no epilogue at all
+    if (p.M > 0) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[MI - 1][3])); return; }
+#endif
     float bias_v[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) bias_v[j] = 0.f;
