@@ -8,7 +8,7 @@ import torch
 from gpu_common import bf16_round, dev, n, rel_err, t
 from oracle import paintmind_oracle as O
 from oracle import vq_ref
-from paintmind_amd import ops, packing
+from paintmind_amd import _lib, ops, packing
 from paintmind_amd._lib import PmhipError
 from util import maxabs
 
@@ -781,6 +781,34 @@ def test_masked_ce_matches_oracle(M, V, eps):
     ref = torch.nn.functional.cross_entropy(torch.from_numpy(logits), torch.from_numpy(labels), label_smoothing=eps,
                                             reduction="none").numpy()
     assert maxabs(n(rows), ref * mask) < 1e-4
+
+
+def test_c_abi_rejects_bad_arguments_with_a_message_and_stays_usable():
+    """Error behaviour of the boundary (include/pmhip.h): a bad call returns a non-zero code, pmhip_last_error() names the
+    problem, nothing is launched, and the library keeps working afterwards -- the Python shim turns the code into PmhipError
+    (a RuntimeError, as the reference raises from torch for the same mistakes)."""
+    bf = torch.bfloat16
+    a = torch.zeros(64, 100, device=dev(), dtype=bf)               # K = 100: not a multiple of 64
+    w = torch.zeros(64, 100, device=dev(), dtype=bf)
+    with pytest.raises(PmhipError, match="multiple of 64"):
+        ops.gemm(a, w)
+    q = torch.zeros(1, 2, 64, 64, device=dev(), dtype=bf)
+    k = torch.zeros(1, 2, 64, 64, device=dev(), dtype=bf)
+    vt = torch.zeros(1, 2, 64, 64, device=dev(), dtype=bf)
+    with pytest.raises(PmhipError, match="Nkv_pad"):
+        ops.attention(q, k, vt, 100)                                # more keys than the padded K / V^T hold
+    logits = torch.zeros(4, 64, device=dev())
+    ids = torch.zeros(4, dtype=torch.int64, device=dev())
+    with pytest.raises(PmhipError, match="topk"):
+        ops.sample_rows(logits, ids, 64, 65, 1.0, noise=torch.full((4, 64), 0.5, device=dev()))
+    lib = _lib.load()
+    assert lib.pmhip_attention(1, None, None, None, None, 64, 1, 1, 64, 64, 64, 1, None) != 0
+    assert b"null" in lib.pmhip_last_error()
+    assert lib.pmhip_timing_get(b"no-such-family", None, None) != 0
+    # ... and the next good call is unaffected
+    a2 = t(bf16_round(rnd(128, 128)), bf)
+    w2 = t(bf16_round(rnd(128, 128)), bf)
+    assert rel_err(n(ops.gemm(a2, w2, out_dtype=torch.float32)), n(a2.float()) @ n(w2.float()).T) < 1e-5
 
 
 def test_masked_ce_nothing_masked_is_nan_and_bad_args_raise():
